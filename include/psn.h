@@ -1,0 +1,141 @@
+/*
+ * libpsn - MI355X (gfx950) min-cost max-flow scheduling solver: C ABI.
+ *
+ * This is the drop-in boundary for the scheduling round that Poseidon triggers with
+ * the Schedule RPC (/root/reference/pkg/firmament/firmament_scheduler.proto:17,
+ * client wrapper /root/reference/pkg/firmament/firmament_client.go:29-35, caller
+ * /root/reference/cmd/poseidon/poseidon.go:34).  In the reference everything behind
+ * that RPC (flow-graph update, arc pricing, min-cost max-flow solve, flow -> deltas)
+ * runs in an external Firmament process that is not part of the repository
+ * (/root/reference/.gitmodules:1-3, /root/reference/deploy/firmament-deployment.yaml:29-30).
+ * A Go server implementing FirmamentSchedulerServer
+ * (/root/reference/pkg/firmament/firmament_scheduler.pb.go:600-614) binds these
+ * entry points through cgo; the declarations use plain pointers and sizes only.
+ *
+ * Conventions
+ *  - every function returns PSN_OK (0) or a negative PSN_E* code; nothing aborts or
+ *    throws across the boundary; psn_strerror() gives the text, psn_last_error()
+ *    the detail (HIP error string) of the last failure on a context;
+ *  - the caller owns every host buffer; the library copies inputs before returning
+ *    and never keeps a caller pointer (cgo rule); outputs are caller-allocated;
+ *  - the library owns all device memory, inside psn_ctx;
+ *  - a psn_ctx is bound to one GPU and is not re-entrant: one call at a time.
+ */
+#ifndef PSN_H_
+#define PSN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSN_OK 0
+#define PSN_EINVAL (-1)      /* bad argument / malformed graph */
+#define PSN_ENOMEM (-2)      /* host or device allocation failed */
+#define PSN_EDEVICE (-3)     /* HIP runtime error (see psn_last_error) */
+#define PSN_EINFEASIBLE (-4) /* supplies cannot be routed */
+#define PSN_EOVERFLOW (-5)   /* cost * (n+1) * bound does not fit int64 */
+#define PSN_ESTATE (-6)      /* call out of order (e.g. solve before upload) */
+#define PSN_ELIMIT (-7)      /* iteration guard tripped without convergence */
+
+typedef struct psn_ctx psn_ctx;
+
+typedef struct psn_config {
+    int32_t device;          /* HIP device ordinal */
+    int32_t alpha_log2;      /* epsilon divisor per refine = 2^alpha_log2 (0 -> default 3) */
+    int32_t rounds_per_batch;/* push/relabel rounds between global price updates (0 -> default) */
+    int32_t flags;           /* PSN_CFG_* */
+} psn_config;
+#define PSN_CFG_EAGER 1      /* plain launches instead of hipGraph replay (debugging) */
+
+/* Result of one solve.  Counters are what the kernels actually did; bytes follow
+ * from them (20 B per arc scan, 36 B per push, 32 B per vertex visit, 8 B per
+ * relabel). */
+typedef struct psn_result {
+    int64_t total_cost;      /* sum over arcs of flow * cost */
+    int32_t status;          /* PSN_OK or PSN_E* */
+    int32_t refines;         /* epsilon phases run */
+    uint64_t arc_scans;      /* residual arcs examined by push/relabel sweeps */
+    uint64_t pushes;
+    uint64_t relabels;
+    uint64_t vertex_visits;  /* active vertices picked up by sweeps */
+    uint64_t gu_arc_scans;   /* residual arcs examined by global price updates */
+    uint64_t gu_relaxations; /* successful distance improvements */
+    uint64_t sat_arc_scans;  /* arcs examined by the per-phase saturation sweep */
+    uint64_t rounds;         /* push/relabel rounds that had work */
+    uint64_t gu_iterations;  /* frontier expansions that had work */
+    uint64_t global_updates;
+    uint64_t launches;       /* kernel launches issued (graph nodes included) */
+    double solve_ms;         /* device time, first refine kernel -> cost readback */
+} psn_result;
+
+#define PSN_WARM_START 1u    /* psn_solve: keep prices and flow from the previous solve */
+
+/* Shape of a psn flow network (vertex id ranges), needed by cost evaluation and
+ * placement extraction.  Vertex ids: 0 sink | 1..N machines | N+1..N+E task
+ * classes | then J unscheduled aggregators | then P tasks. */
+typedef struct psn_layout {
+    int32_t n_machines, n_classes, n_jobs, n_tasks, k_slots;
+} psn_layout;
+
+int psn_version(void);
+const char *psn_strerror(int code);
+const char *psn_last_error(const psn_ctx *ctx);
+
+/* Lifetime.  Replaces connecting to the Firmament service
+ * (/root/reference/pkg/firmament/firmament_client.go:211-221). */
+int psn_create(const psn_config *cfg, psn_ctx **out);
+void psn_destroy(psn_ctx *ctx);
+
+/* Hand the flow network to the device as residual CSR: arcs grouped by tail,
+ * row_off[n+1]; for each residual arc head, residual capacity, cost (reverse arc
+ * carries -cost) and the index of its paired arc.  supply[n] sums to zero.
+ * This is what the reference's TaskSubmitted / NodeAdded stream
+ * (/root/reference/pkg/firmament/firmament_scheduler.proto:26,31) accumulates
+ * into inside Firmament before a Schedule call. */
+int psn_upload_csr(psn_ctx *ctx, int32_t n, int64_t m2, const int64_t *row_off,
+                   const int32_t *head, const int32_t *cap, const int32_t *cost,
+                   const int32_t *rev, const int64_t *supply);
+
+/* CPU/memory arc-cost model on the device: prices every (task class e, machine m,
+ * slot k) arc of the uploaded network in place (cost and capacity of the forward
+ * arc, -cost / 0 on its reverse).  ec_arc_base[e] is the index of class e's first
+ * slot arc; arcs of one class are laid out machine-major, slot-minor.  Stands in
+ * for Firmament's cpu/mem cost model selected at
+ * /root/reference/deploy/firmament-deployment.yaml:29 with the units of
+ * /root/reference/pkg/k8sclient/podwatcher.go:382-386 (millicores, Kb). */
+int psn_eval_costs(psn_ctx *ctx, const psn_layout *layout, const int64_t *cap_cpu,
+                   const int64_t *cap_mem, const int64_t *used_cpu, const int64_t *used_mem,
+                   const int64_t *req_cpu, const int64_t *req_mem, const int64_t *ec_arc_base);
+
+/* Overwrite residual capacities / supplies of the uploaded network (same layout),
+ * for incremental re-solves: entries are (arc index, new original capacity) and
+ * (vertex, new supply).  With PSN_WARM_START the next solve repairs the kept flow. */
+int psn_update_caps(psn_ctx *ctx, int64_t count, const int64_t *arc_index, const int32_t *new_cap);
+int psn_update_supplies(psn_ctx *ctx, int64_t count, const int32_t *vertex, const int64_t *new_supply);
+
+/* The scheduling solve itself: cost-scaling push-relabel on the device.  Replaces
+ * the solver run inside Firmament's Schedule handler
+ * (/root/reference/pkg/firmament/firmament_scheduler.proto:17). */
+int psn_solve(psn_ctx *ctx, uint32_t flags, psn_result *out);
+
+/* Read back: flow on every residual arc (original minus residual capacity, >= 0 on
+ * arcs carrying flow, <= 0 on their pairs), scaled prices (1-optimal for costs
+ * multiplied by n+1), and task -> machine index (-1 = unscheduled) for psn-layout
+ * networks.  Placements feed the SchedulingDelta list the caller returns
+ * (/root/reference/pkg/firmament/scheduling_delta.proto:25-41). */
+int psn_get_flow(psn_ctx *ctx, int32_t *flow /* m2 */);
+int psn_get_residual(psn_ctx *ctx, int32_t *cap /* m2 */);
+int psn_get_prices(psn_ctx *ctx, int64_t *price /* n */);
+int psn_get_costs(psn_ctx *ctx, int32_t *cost /* m2 */, int32_t *cap_orig /* m2 */);
+int psn_get_placements(psn_ctx *ctx, const psn_layout *layout, int32_t *task_to_machine /* P */);
+
+/* Device pointer to the last placements (int32[P]) for collectives that gather
+ * placements across GPUs without a host round trip; valid until the next call. */
+int psn_placements_device_ptr(psn_ctx *ctx, void **dptr, int64_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSN_H_ */

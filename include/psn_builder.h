@@ -1,0 +1,54 @@
+/*
+ * libpsn flow-graph builder: host-side C ABI above the solver (include/psn.h).
+ *
+ * In the new split the Go server keeps the protobuf surface
+ * (/root/reference/pkg/firmament/firmament_scheduler.pb.go:600-614) and turns the
+ * accumulated tasks (/root/reference/pkg/k8sclient/podwatcher.go:377-410) and machines
+ * (/root/reference/pkg/k8sclient/nodewatcher.go:292-339, one PU per machine) into the
+ * task -> class -> machine -> sink flow network.  These entry points are that builder,
+ * written in C++ because no Go toolchain is available; the Go side would call them
+ * through cgo exactly as it calls psn_upload_csr.
+ */
+#ifndef PSN_BUILDER_H_
+#define PSN_BUILDER_H_
+
+#include <stdint.h>
+#include "psn.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSN_UNSCHED_COST 2560000 /* cost of leaving a task unscheduled */
+#define PSN_SLOTS 12             /* task slots per machine (machine -> sink capacity) */
+#define PSN_KSLOTS 8             /* parallel unit arcs per (class, machine) pair */
+#define PSN_NCLASSES 64          /* request shapes: 8 cpu x 8 memory sizes */
+
+/* Deterministic synthetic cluster (family psn-synth-v1): splitmix64 seeded with
+ * 0x506F736569646F6E ^ (config_id << 32) ^ seed; per machine four draws (cpu size,
+ * GiB per core, used cpu permille, used mem permille), then per task two draws
+ * (class, job); every draw is next() % range.  CPU in millicores and memory in Kb,
+ * the units the reference sends (/root/reference/pkg/k8sclient/podwatcher.go:382-386).
+ * All arrays are caller-allocated: machines N, classes E (= 64), tasks P. */
+int psn_synth_cluster(int32_t config_id, uint64_t seed, const psn_layout *layout, int64_t *cap_cpu,
+                      int64_t *cap_mem, int64_t *used_cpu, int64_t *used_mem, int64_t *req_cpu,
+                      int64_t *req_mem, int32_t *task_class, int32_t *task_job);
+
+/* Vertex and residual-arc counts of the network for a layout. */
+int psn_network_size(const psn_layout *layout, int32_t *n, int64_t *m2);
+
+/* Residual CSR of the network (arrays sized by psn_network_size).  Slot arcs
+ * (class -> machine) are emitted with cost 0 and capacity 0; psn_eval_costs prices
+ * them on the device.  ec_arc_base[E] receives the index of each class's first slot arc. */
+int psn_build_network(const psn_layout *layout, int32_t slots, int32_t unsched_cost,
+                      const int32_t *task_class, const int32_t *task_job, int64_t *row_off,
+                      int32_t *head, int32_t *cap, int32_t *cost, int32_t *rev, int64_t *supply,
+                      int64_t *ec_arc_base);
+
+/* FNV-1a-64 over a byte range, chained through h (start with 0xCBF29CE484222325). */
+uint64_t psn_fnv1a64(const void *data, int64_t nbytes, uint64_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSN_BUILDER_H_ */

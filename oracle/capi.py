@@ -1,0 +1,120 @@
+"""ORACLE (test infrastructure): ctypes loader for oracle/psn_oracle.c.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The shared object is built by ``oracle/Makefile`` (plain gcc).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "build", "libpsn_oracle.so")
+
+
+class Stats(C.Structure):
+    _fields_ = [("pushes", C.c_int64), ("relabels", C.c_int64), ("arc_scans", C.c_int64),
+                ("global_updates", C.c_int64), ("refines", C.c_int64), ("solve_ms", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "psn_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.psn_oracle_fnv1a64.restype = C.c_uint64
+        _lib.psn_oracle_fnv1a64.argtypes = [C.c_void_p, C.c_int64, C.c_uint64]
+        _lib.psn_oracle_check_eps.restype = C.c_int64
+    return _lib
+
+
+def _p(a, dtype):
+    assert a.dtype == dtype and a.flags["C_CONTIGUOUS"], (a.dtype, dtype)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def fnv1a64(*arrays) -> int:
+    h = 0xCBF29CE484222325
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h = lib().psn_oracle_fnv1a64(a.ctypes.data_as(C.c_void_p), C.c_int64(a.nbytes), C.c_uint64(h))
+    return int(h)
+
+
+def csr_checksum(g) -> int:
+    return fnv1a64(g.row_off, g.head, g.cap, g.cost, g.rev, g.supply)
+
+
+def eval_costs(cl):
+    E, N, K = cl.req_cpu.shape[0], cl.n_machines, cl.k_slots
+    cost = np.empty((E, N, K), np.int32)
+    cap = np.empty((E, N, K), np.int32)
+    lib().psn_oracle_eval_costs(C.c_int32(E), C.c_int32(N), C.c_int32(K),
+                                _p(cl.req_cpu, np.int64), _p(cl.req_mem, np.int64),
+                                _p(cl.cap_cpu, np.int64), _p(cl.cap_mem, np.int64),
+                                _p(cl.used_cpu, np.int64), _p(cl.used_mem, np.int64),
+                                _p(cost, np.int32), _p(cap, np.int32))
+    return cost, cap
+
+
+def ssp(g):
+    """-> (rc, total_cost, residual_cap, potentials)"""
+    cap = g.cap.copy()
+    tc = C.c_int64(0)
+    pot = np.zeros(g.n, np.int64)
+    rc = lib().psn_oracle_ssp(C.c_int32(g.n), C.c_int64(2 * g.m), _p(g.row_off, np.int64),
+                              _p(g.head, np.int32), _p(cap, np.int32), _p(g.cost, np.int32),
+                              _p(g.rev, np.int32), _p(g.supply, np.int64), C.byref(tc),
+                              _p(pot, np.int64))
+    return rc, tc.value, cap, pot
+
+
+def cost_scaling(g, alpha: int = 12):
+    """-> (rc, total_cost, residual_cap, scaled_prices, Stats)"""
+    cap = g.cap.copy()
+    tc = C.c_int64(0)
+    price = np.zeros(g.n, np.int64)
+    st = Stats()
+    rc = lib().psn_oracle_cost_scaling(C.c_int32(g.n), C.c_int64(2 * g.m), _p(g.row_off, np.int64),
+                                       _p(g.head, np.int32), _p(cap, np.int32),
+                                       _p(g.cost, np.int32), _p(g.rev, np.int32),
+                                       _p(g.supply, np.int64), C.c_int32(alpha), C.byref(tc),
+                                       _p(price, np.int64), C.byref(st))
+    return rc, tc.value, cap, price, st
+
+
+def check(g, cap_final, price_hint=None):
+    """Certificate.  -> (rc, total_cost, potentials); rc 0 = feasible and optimal,
+    1 = conservation, 2 = bounds/structure, 3 = not optimal."""
+    tc = C.c_int64(0)
+    pot = np.zeros(g.n, np.int64)
+    cap_final = np.ascontiguousarray(cap_final, dtype=np.int32)
+    hint = None if price_hint is None else _p(np.ascontiguousarray(price_hint, np.int64), np.int64)
+    rc = lib().psn_oracle_check(C.c_int32(g.n), C.c_int64(2 * g.m), _p(g.row_off, np.int64),
+                                _p(g.head, np.int32), _p(g.cap, np.int32), _p(cap_final, np.int32),
+                                _p(g.cost, np.int32), _p(g.rev, np.int32), _p(g.supply, np.int64),
+                                hint, C.byref(tc), _p(pot, np.int64))
+    return rc, tc.value, pot
+
+
+def check_eps(g, cap_final, price, eps: int = 1) -> int:
+    """Number of residual arcs violating eps-optimality under scaled prices (-1: eps too big)."""
+    cap_final = np.ascontiguousarray(cap_final, dtype=np.int32)
+    price = np.ascontiguousarray(price, dtype=np.int64)
+    return int(lib().psn_oracle_check_eps(C.c_int32(g.n), C.c_int64(2 * g.m), _p(g.row_off, np.int64),
+                                          _p(g.head, np.int32), _p(cap_final, np.int32),
+                                          _p(g.cost, np.int32), _p(price, np.int64), C.c_int64(eps)))

@@ -1,0 +1,103 @@
+"""ctypes binding of libpsn.so (include/psn.h, include/psn_builder.h).
+
+The library is HIP-only: there is no CPU implementation behind these calls.  If
+the shared object is missing, or no GPU is present when a context is created, the
+call raises instead of falling back to anything else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsn.so")
+
+PSN_OK = 0
+PSN_EINVAL, PSN_ENOMEM, PSN_EDEVICE, PSN_EINFEASIBLE = -1, -2, -3, -4
+PSN_EOVERFLOW, PSN_ESTATE, PSN_ELIMIT = -5, -6, -7
+PSN_WARM_START = 1
+PSN_CFG_EAGER = 1
+
+EXPORTS = [
+    "psn_version", "psn_strerror", "psn_last_error", "psn_create", "psn_destroy",
+    "psn_upload_csr", "psn_eval_costs", "psn_update_caps", "psn_update_supplies", "psn_solve",
+    "psn_get_flow", "psn_get_residual", "psn_get_prices", "psn_get_costs", "psn_get_placements",
+    "psn_placements_device_ptr",
+    "psn_synth_cluster", "psn_network_size", "psn_build_network", "psn_fnv1a64",
+]
+
+
+class PsnError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        super().__init__(f"libpsn error {code}: {detail}")
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("alpha_log2", C.c_int32), ("rounds_per_batch", C.c_int32),
+                ("flags", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("total_cost", C.c_int64), ("status", C.c_int32), ("refines", C.c_int32),
+                ("arc_scans", C.c_uint64), ("pushes", C.c_uint64), ("relabels", C.c_uint64),
+                ("vertex_visits", C.c_uint64), ("gu_arc_scans", C.c_uint64),
+                ("gu_relaxations", C.c_uint64), ("sat_arc_scans", C.c_uint64), ("rounds", C.c_uint64),
+                ("gu_iterations", C.c_uint64), ("global_updates", C.c_uint64), ("launches", C.c_uint64),
+                ("solve_ms", C.c_double)]
+
+
+class Layout(C.Structure):
+    _fields_ = [("n_machines", C.c_int32), ("n_classes", C.c_int32), ("n_jobs", C.c_int32),
+                ("n_tasks", C.c_int32), ("k_slots", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libpsn.so from the package directory (built in-tree by `make`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PsnError(PSN_EDEVICE, f"{LIB_PATH} is missing: run `make` (hipcc, gfx950) first")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32
+    lib.psn_version.restype = C.c_int
+    lib.psn_strerror.restype = C.c_char_p
+    lib.psn_strerror.argtypes = [C.c_int]
+    lib.psn_last_error.restype = C.c_char_p
+    lib.psn_last_error.argtypes = [vp]
+    lib.psn_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.psn_destroy.argtypes = [vp]
+    lib.psn_destroy.restype = None
+    lib.psn_upload_csr.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp]
+    lib.psn_eval_costs.argtypes = [vp, C.POINTER(Layout), vp, vp, vp, vp, vp, vp, vp]
+    lib.psn_update_caps.argtypes = [vp, i64, vp, vp]
+    lib.psn_update_supplies.argtypes = [vp, i64, vp, vp]
+    lib.psn_solve.argtypes = [vp, u32, C.POINTER(Result)]
+    lib.psn_get_flow.argtypes = [vp, vp]
+    lib.psn_get_residual.argtypes = [vp, vp]
+    lib.psn_get_prices.argtypes = [vp, vp]
+    lib.psn_get_costs.argtypes = [vp, vp, vp]
+    lib.psn_get_placements.argtypes = [vp, C.POINTER(Layout), vp]
+    lib.psn_placements_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    lib.psn_synth_cluster.argtypes = [i32, u64, C.POINTER(Layout), vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.psn_network_size.argtypes = [C.POINTER(Layout), C.POINTER(i32), C.POINTER(i64)]
+    lib.psn_build_network.argtypes = [C.POINTER(Layout), i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.psn_fnv1a64.restype = u64
+    lib.psn_fnv1a64.argtypes = [vp, i64, u64]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, ctx=None):
+    if rc != PSN_OK:
+        lib = load_library()
+        detail = lib.psn_strerror(rc).decode()
+        if ctx:
+            extra = lib.psn_last_error(ctx).decode()
+            if extra:
+                detail += " (" + extra + ")"
+        raise PsnError(rc, detail)

@@ -1,0 +1,545 @@
+// libpsn host side: the C ABI declared in include/psn.h.  Owns device memory, validates
+// what crosses the boundary, records the sweep sequence into a hipGraph and replays it
+// until the device-resident control block reports completion.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/psn.h"
+#include "psn_device.h"
+#include "psn_kernels.hip"  // one translation unit: kernels are launched from this file
+
+using namespace psn;
+
+struct psn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    psn_config cfg{};
+    std::string err;
+    // sizes
+    int n = 0;
+    long long m2 = 0;
+    long long high_items = 0;
+    bool uploaded = false, solved = false;
+    DevGraph g{};
+    // owned device buffers
+    std::vector<void *> bufs;
+    i64 *d_supply = nullptr;
+    int *d_cost = nullptr, *d_ocap = nullptr;  // non-const aliases of g.cost / g.ocap
+    i64 *d_scalar = nullptr;                   // [0] total cost, [1] max |cost|, [2] max violation
+    unsigned long long *d_tally_out = nullptr;
+    int tally_slots = 0;
+    // placements scratch
+    int *d_place = nullptr, *d_slot_machine = nullptr;
+    long long place_count = 0, slot_stride = 0, slot_classes = 0;
+    // graph replay
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    int rounds = 8;
+    int launches_per_replay = 0;
+    Ctrl *h_ctrl = nullptr;  // pinned
+};
+
+namespace {
+
+int fail(psn_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+    if (c) {
+        c->err = what ? what : "";
+        if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+#define HIPCHK(c, call)                                                   \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) return fail((c), PSN_EDEVICE, #call, e_);   \
+    } while (0)
+
+template <typename T>
+int dalloc(psn_ctx *c, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(c, PSN_ENOMEM, "hipMalloc", e);
+    c->bufs.push_back(q);
+    *p = static_cast<T *>(q);
+    return PSN_OK;
+}
+void free_graph_buffers(psn_ctx *c) {
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    for (void *p : c->bufs) (void)hipFree(p);
+    c->bufs.clear();
+    c->uploaded = c->solved = false;
+    c->d_place = c->d_slot_machine = nullptr;
+    c->place_count = c->slot_stride = c->slot_classes = 0;
+}
+
+// The fixed launch sequence of one replay; `count_only` just counts the launches.
+int enqueue_replay(psn_ctx *c, hipStream_t s) {
+    const DevGraph &g = c->g;
+    int launches = 0;
+#define L(kern, grid, ...)                                                \
+    do {                                                                  \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, __VA_ARGS__); \
+        ++launches;                                                       \
+    } while (0)
+    hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, g); ++launches;
+    L(k_saturate, kGrid, g);
+    L(k_gu_init, kGrid, g);
+    for (int k = 0; k < kGuIters; ++k) L(k_gu_expand, kGrid, g, k);
+    hipLaunchKernelGGL(k_mid, dim3(1), dim3(1), 0, s, g, kGuIters); ++launches;
+    L(k_gu_dmax, kGrid, g);
+    L(k_gu_apply, kGrid, g);
+    L(k_relabel_compact, kGrid, g, 0, 0);
+    for (int k = 0; k < c->rounds; ++k) {
+        L(k_push, kGrid, g, k);
+        L(k_relabel_compact, kGrid, g, k, 1);
+    }
+    hipLaunchKernelGGL(k_end, dim3(1), dim3(1), 0, s, g, c->rounds); ++launches;
+#undef L
+    c->launches_per_replay = launches;
+    return PSN_OK;
+}
+
+int build_graph(psn_ctx *c) {
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    if (c->cfg.flags & PSN_CFG_EAGER) return PSN_OK;
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_replay(c, c->stream);
+    HIPCHK(c, hipStreamEndCapture(c->stream, &c->graph));
+    HIPCHK(c, hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0));
+    return PSN_OK;
+}
+
+__global__ void k_max_abs_cost(DevGraph g, i64 *out) {
+    i64 mx = 0;
+    for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) {
+        if (g.ocap[a] > 0 || g.ocap[g.rev[a]] > 0) { i64 c = g.cost[a]; c = c < 0 ? -c : c; mx = c > mx ? c : mx; }
+    }
+    for (int d = 32; d; d >>= 1) { i64 y = __shfl_xor(mx, d); mx = y > mx ? y : mx; }
+    if ((threadIdx.x & 63) == 0 && mx > 0) __hip_atomic_fetch_max(out, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Largest amount by which a residual arc's reduced cost is below zero (warm start).
+__global__ void k_max_violation(DevGraph g, i64 *out) {
+    i64 mx = 0;
+    for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) {
+        if (g.cap[a] > 0) {
+            i64 rc = (i64)g.cost[a] * g.scale + g.price[g.tail[a]] - g.price[g.head[a]];
+            if (-rc > mx) mx = -rc;
+        }
+    }
+    for (int d = 32; d; d >>= 1) { i64 y = __shfl_xor(mx, d); mx = y > mx ? y : mx; }
+    if ((threadIdx.x & 63) == 0 && mx > 0) __hip_atomic_fetch_max(out, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int ceil_log2(i64 x) {
+    int s = 0;
+    while (((i64)1 << s) < x && s < 62) ++s;
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psn_version(void) { return 100; }
+
+const char *psn_strerror(int code) {
+    switch (code) {
+        case PSN_OK: return "ok";
+        case PSN_EINVAL: return "invalid argument or malformed graph";
+        case PSN_ENOMEM: return "out of memory";
+        case PSN_EDEVICE: return "HIP runtime error";
+        case PSN_EINFEASIBLE: return "supplies cannot be routed (infeasible)";
+        case PSN_EOVERFLOW: return "scaled costs do not fit 64-bit arithmetic";
+        case PSN_ESTATE: return "call out of order";
+        case PSN_ELIMIT: return "iteration guard tripped";
+        default: return "unknown error";
+    }
+}
+
+const char *psn_last_error(const psn_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int psn_create(const psn_config *cfg, psn_ctx **out) {
+    if (!out) return PSN_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PSN_EDEVICE;  // no GPU: fail loudly
+    psn_ctx *c = new (std::nothrow) psn_ctx();
+    if (!c) return PSN_ENOMEM;
+    if (cfg) c->cfg = *cfg;
+    if (c->cfg.alpha_log2 <= 0 || c->cfg.alpha_log2 > 8) c->cfg.alpha_log2 = 3;
+    c->rounds = c->cfg.rounds_per_batch > 0 ? c->cfg.rounds_per_batch : 8;
+    if (c->rounds & 1) ++c->rounds;  // list parity must be the same at every replay start
+    if (c->rounds > 62) c->rounds = 62;
+    c->device = c->cfg.device;
+    if (c->device < 0 || c->device >= ndev) { delete c; return PSN_EINVAL; }
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_ctrl, sizeof(Ctrl), hipHostMallocDefault);
+    if (e != hipSuccess) { psn_destroy(c); return PSN_EDEVICE; }
+    *out = c;
+    return PSN_OK;
+}
+
+void psn_destroy(psn_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_graph_buffers(c);
+    if (c->h_ctrl) (void)hipHostFree(c->h_ctrl);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, const int32_t *head, const int32_t *cap,
+                   const int32_t *cost, const int32_t *rev, const int64_t *supply) {
+    if (!c) return PSN_EINVAL;
+    if (n <= 0 || m2 < 0 || m2 >= (int64_t)0x7FFFFFF0 || !row_off || !supply || (m2 > 0 && (!head || !cap || !cost || !rev)))
+        return fail(c, PSN_EINVAL, "null or out-of-range argument");
+    // ---- validate on the host: a malformed graph must never reach a kernel
+    if (row_off[0] != 0 || row_off[n] != m2) return fail(c, PSN_EINVAL, "row_off[0] != 0 or row_off[n] != m2");
+    for (int32_t v = 0; v < n; ++v)
+        if (row_off[v + 1] < row_off[v]) return fail(c, PSN_EINVAL, "row_off not monotone");
+    int64_t ssum = 0;
+    for (int32_t v = 0; v < n; ++v) ssum += supply[v];
+    if (ssum != 0) return fail(c, PSN_EINFEASIBLE, "supplies do not sum to zero");
+    std::vector<int> tail((size_t)m2);
+    for (int32_t v = 0; v < n; ++v)
+        for (int64_t a = row_off[v]; a < row_off[v + 1]; ++a) tail[(size_t)a] = v;
+    int64_t max_abs = 0;
+    for (int64_t a = 0; a < m2; ++a) {
+        const int32_t r = rev[a];
+        if (head[a] < 0 || head[a] >= n) return fail(c, PSN_EINVAL, "head out of range");
+        if (r < 0 || r >= m2 || rev[r] != a || r == a) return fail(c, PSN_EINVAL, "rev is not an involution");
+        if (head[r] != tail[(size_t)a]) return fail(c, PSN_EINVAL, "rev does not point at the reverse arc");
+        if (cost[r] != -cost[a]) return fail(c, PSN_EINVAL, "cost[rev[a]] != -cost[a]");
+        if (cap[a] < 0) return fail(c, PSN_EINVAL, "negative capacity");
+        if ((int64_t)cap[a] + cap[r] > INT32_MAX) return fail(c, PSN_EOVERFLOW, "capacity pair overflows int32");
+        const int64_t ac = cost[a] < 0 ? -(int64_t)cost[a] : cost[a];
+        if (ac > max_abs) max_abs = ac;
+    }
+    {   // price magnitudes stay below ~ 8 * n * max|cost| * (n+1)
+        const long double bound = 8.0L * (long double)n * (long double)(max_abs + 1) * (long double)(n + 1);
+        if (bound > 4.0e18L) return fail(c, PSN_EOVERFLOW, "n^2 * max|cost| too large for int64 prices");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_graph_buffers(c);
+    c->n = n;
+    c->m2 = m2;
+    // ---- classify vertices by degree
+    std::vector<unsigned> row((size_t)n + 1);
+    std::vector<unsigned char> cls((size_t)n);
+    long long high_items = 0;
+    for (int32_t v = 0; v <= n; ++v) row[(size_t)v] = (unsigned)row_off[v];
+    for (int32_t v = 0; v < n; ++v) {
+        const unsigned deg = row[(size_t)v + 1] - row[(size_t)v];
+        cls[(size_t)v] = deg <= kLowMax ? kClsLow : (deg <= kMedMax ? kClsMed : kClsHigh);
+        if (deg > kMedMax) high_items += (deg + kWSeg - 1) / kWSeg;
+    }
+    c->high_items = high_items;
+    // ---- allocate
+    DevGraph &g = c->g;
+    g = DevGraph{};
+    g.n = n;
+    g.m2 = (unsigned)m2;
+    g.scale = (i64)n + 1;
+    unsigned *d_row; int *d_head, *d_rev, *d_tail; unsigned char *d_cls;
+    int rc;
+#define A(p, cnt) if ((rc = dalloc(c, &(p), (size_t)(cnt))) != PSN_OK) { free_graph_buffers(c); return rc; }
+    A(d_row, n + 1) A(d_head, m2) A(c->d_cost, m2) A(d_rev, m2) A(d_tail, m2) A(c->d_ocap, m2) A(d_cls, n)
+    A(g.cap, m2) A(g.rcap, m2) A(g.price, n) A(g.excess, n) A(g.cand, n) A(g.dist, n) A(g.fstamp, n)
+    A(c->d_supply, n) A(c->d_scalar, 8)
+    for (int i = 0; i < 2; ++i) { A(g.list_low[i], n) A(g.list_med[i], n) A(g.list_high[i], high_items) }
+    for (int i = 0; i < 3; ++i) { A(g.fr_low[i], n) A(g.fr_med[i], n) A(g.fr_high[i], high_items) }
+    c->tally_slots = kGrid * (kBlock / 64);
+    A(g.tally, (size_t)c->tally_slots * kTallyN) A(c->d_tally_out, kTallyN) A(g.ctrl, 1)
+#undef A
+    g.row = d_row; g.head = d_head; g.cost = c->d_cost; g.rev = d_rev; g.tail = d_tail; g.ocap = c->d_ocap; g.cls = d_cls;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(d_row, row.data(), sizeof(unsigned) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_cls, cls.data(), (size_t)n, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_tail, tail.data(), sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_head, head, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_cost, cost, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_rev, rev, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_ocap, cap, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(g.cap, cap, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_supply, supply, sizeof(i64) * (size_t)n, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(g.price, 0, sizeof(i64) * (size_t)n, s));
+    HIPCHK(c, hipStreamSynchronize(s));  // host staging vectors die at return
+    if ((rc = build_graph(c)) != PSN_OK) { free_graph_buffers(c); return rc; }
+    c->uploaded = true;
+    return PSN_OK;
+}
+
+int psn_eval_costs(psn_ctx *c, const psn_layout *lay, const int64_t *cap_cpu, const int64_t *cap_mem, const int64_t *used_cpu,
+                   const int64_t *used_mem, const int64_t *req_cpu, const int64_t *req_mem, const int64_t *ec_arc_base) {
+    if (!c || !lay || !cap_cpu || !cap_mem || !used_cpu || !used_mem || !req_cpu || !req_mem || !ec_arc_base)
+        return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    const int N = lay->n_machines, E = lay->n_classes, K = lay->k_slots;
+    if (N <= 0 || E <= 0 || K <= 0) return fail(c, PSN_EINVAL, "bad layout");
+    for (int e = 0; e < E; ++e) {
+        if (req_cpu[e] <= 0 || req_mem[e] <= 0) return fail(c, PSN_EINVAL, "request must be positive");
+        if (ec_arc_base[e] < 0 || ec_arc_base[e] + (int64_t)N * K > c->m2) return fail(c, PSN_EINVAL, "ec_arc_base out of range");
+    }
+    for (int m = 0; m < N; ++m) {
+        if (cap_cpu[m] <= 0 || cap_mem[m] <= 0 || used_cpu[m] < 0 || used_mem[m] < 0)
+            return fail(c, PSN_EINVAL, "machine capacity must be positive, usage non-negative");
+        // largest intermediate: 1000 * (used + K * req) must stay in int64 and the cost in int32
+        if (cap_mem[m] > (int64_t)4e15 || used_mem[m] > (int64_t)4e15 || cap_cpu[m] > (int64_t)4e15 || used_cpu[m] > (int64_t)4e15)
+            return fail(c, PSN_EOVERFLOW, "machine quantity too large");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    i64 *d;  // one staging allocation: 4 machine arrays, 2 shape arrays, bases
+    const size_t cnt = 4 * (size_t)N + 3 * (size_t)E;
+    HIPCHK(c, hipMalloc((void **)&d, cnt * sizeof(i64)));
+    std::vector<i64> h(cnt);
+    std::copy(cap_cpu, cap_cpu + N, h.begin());
+    std::copy(cap_mem, cap_mem + N, h.begin() + N);
+    std::copy(used_cpu, used_cpu + N, h.begin() + 2 * (size_t)N);
+    std::copy(used_mem, used_mem + N, h.begin() + 3 * (size_t)N);
+    std::copy(req_cpu, req_cpu + E, h.begin() + 4 * (size_t)N);
+    std::copy(req_mem, req_mem + E, h.begin() + 4 * (size_t)N + E);
+    std::copy(ec_arc_base, ec_arc_base + E, h.begin() + 4 * (size_t)N + 2 * (size_t)E);
+    hipError_t e = hipMemcpyAsync(d, h.data(), cnt * sizeof(i64), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const long long total = (long long)E * N;
+        const int grid = (int)std::min<long long>((total + kBlock - 1) / kBlock, 4096);
+        hipLaunchKernelGGL(k_eval_costs, dim3(grid), dim3(kBlock), 0, c->stream, c->g, E, N, K, d, d + N, d + 2 * (size_t)N,
+                           d + 3 * (size_t)N, d + 4 * (size_t)N, d + 4 * (size_t)N + E, d + 4 * (size_t)N + 2 * (size_t)E, c->d_cost,
+                           c->d_ocap);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_eval_costs", e);
+    c->solved = false;  // the flow on re-priced arcs was reset
+    return PSN_OK;
+}
+
+int psn_update_caps(psn_ctx *c, int64_t count, const int64_t *arc_index, const int32_t *new_cap) {
+    if (!c || count < 0 || (count > 0 && (!arc_index || !new_cap))) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    if (count == 0) return PSN_OK;
+    for (int64_t i = 0; i < count; ++i)
+        if (arc_index[i] < 0 || arc_index[i] >= c->m2 || new_cap[i] < 0) return fail(c, PSN_EINVAL, "arc index or capacity out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    i64 *d_idx; int *d_cap;
+    HIPCHK(c, hipMalloc((void **)&d_idx, (size_t)count * sizeof(i64)));
+    hipError_t e = hipMalloc((void **)&d_cap, (size_t)count * sizeof(int));
+    if (e != hipSuccess) { (void)hipFree(d_idx); return fail(c, PSN_ENOMEM, "hipMalloc", e); }
+    e = hipMemcpyAsync(d_idx, arc_index, (size_t)count * sizeof(i64), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cap, new_cap, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const int grid = (int)std::min<long long>((count + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(k_scatter_caps, dim3(grid), dim3(kBlock), 0, c->stream, c->g, (long long)count, d_idx, d_cap, c->d_ocap);
+        hipLaunchKernelGGL(k_clamp_flow, dim3(kGrid), dim3(kBlock), 0, c->stream, c->g);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_idx); (void)hipFree(d_cap);
+    if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_update_caps", e);
+    return PSN_OK;
+}
+
+int psn_update_supplies(psn_ctx *c, int64_t count, const int32_t *vertex, const int64_t *new_supply) {
+    if (!c || count < 0 || (count > 0 && (!vertex || !new_supply))) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    if (count == 0) return PSN_OK;
+    for (int64_t i = 0; i < count; ++i)
+        if (vertex[i] < 0 || vertex[i] >= c->n) return fail(c, PSN_EINVAL, "vertex out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    int *d_v; i64 *d_s;
+    HIPCHK(c, hipMalloc((void **)&d_v, (size_t)count * sizeof(int)));
+    hipError_t e = hipMalloc((void **)&d_s, (size_t)count * sizeof(i64));
+    if (e != hipSuccess) { (void)hipFree(d_v); return fail(c, PSN_ENOMEM, "hipMalloc", e); }
+    e = hipMemcpyAsync(d_v, vertex, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_s, new_supply, (size_t)count * sizeof(i64), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const int grid = (int)std::min<long long>((count + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(k_scatter_supply, dim3(grid), dim3(kBlock), 0, c->stream, (long long)count, d_v, d_s, c->d_supply);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_v); (void)hipFree(d_s);
+    if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_update_supplies", e);
+    return PSN_OK;
+}
+
+int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
+    if (!c || !out) return fail(c, PSN_EINVAL, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    const bool warm = (flags & PSN_WARM_START) && c->solved;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const DevGraph &g = c->g;
+    // supplies must still balance (psn_update_supplies may have changed them)
+    HIPCHK(c, hipEventRecord(c->ev0, s));
+    hipLaunchKernelGGL(k_reset, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_supply, warm ? 1 : 0);
+    hipLaunchKernelGGL(k_mirror, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_supply, warm ? 1 : 0);
+    if (warm) hipLaunchKernelGGL(k_excess_from_flow, dim3(kGrid), dim3(kBlock), 0, s, g);
+    HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 8 * sizeof(i64), s));
+    HIPCHK(c, hipMemsetAsync(g.tally, 0, (size_t)c->tally_slots * kTallyN * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_max_abs_cost, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 1);
+    if (warm) hipLaunchKernelGGL(k_max_violation, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 2);
+    i64 h_scalar[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(h_scalar, c->d_scalar, sizeof(h_scalar), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    Ctrl init{};
+    init.alpha_log2 = c->cfg.alpha_log2;
+    int shift0;
+    if (!warm) {
+        const i64 maxc = std::max<i64>(1, h_scalar[1]) * g.scale;
+        shift0 = ceil_log2(maxc) - init.alpha_log2;
+    } else {
+        // the kept pseudoflow is v-optimal for v = largest violation: resume one step below it
+        shift0 = h_scalar[2] > 1 ? ceil_log2(h_scalar[2]) - init.alpha_log2 : 0;
+    }
+    if (shift0 < 0) shift0 = 0;
+    init.eps_shift = shift0;
+    init.eps = (i64)1 << shift0;
+    init.need_sat = 1;
+    *c->h_ctrl = init;
+    HIPCHK(c, hipMemcpyAsync(g.ctrl, c->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice, s));
+    // ---- replay until done
+    const long long max_replays = 200000;
+    long long replays = 0;
+    int status = PSN_OK;
+    for (;;) {
+        if (c->gexec) {
+            HIPCHK(c, hipGraphLaunch(c->gexec, s));
+        } else {
+            enqueue_replay(c, s);
+            HIPCHK(c, hipGetLastError());
+        }
+        ++replays;
+        HIPCHK(c, hipMemcpyAsync(c->h_ctrl, g.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->h_ctrl->error) { status = c->h_ctrl->error == PSN_EINFEASIBLE_DEV ? PSN_EINFEASIBLE : PSN_EDEVICE; break; }
+        if (c->h_ctrl->done) break;
+        if (replays >= max_replays) { status = PSN_ELIMIT; break; }
+    }
+    hipLaunchKernelGGL(k_total_cost, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar);
+    hipLaunchKernelGGL(k_tally_sum, dim3(1), dim3(64 * kTallyN), 0, s, g, c->d_tally_out, c->tally_slots);
+    unsigned long long h_tally[kTallyN];
+    HIPCHK(c, hipMemcpyAsync(h_scalar, c->d_scalar, sizeof(i64), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(h_tally, c->d_tally_out, sizeof(h_tally), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(c->ev1, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    out->total_cost = h_scalar[0];
+    out->status = status;
+    out->refines = (int32_t)c->h_ctrl->tally_refines;
+    out->arc_scans = h_tally[kTallyScans];
+    out->pushes = h_tally[kTallyPushes];
+    out->relabels = h_tally[kTallyRelabels];
+    out->vertex_visits = h_tally[kTallyVisits];
+    out->gu_arc_scans = h_tally[kTallyGuScans];
+    out->gu_relaxations = h_tally[kTallyGuRelax];
+    out->sat_arc_scans = h_tally[kTallySat];
+    out->rounds = h_tally[kTallyRounds];
+    out->gu_iterations = h_tally[kTallyGuIters];
+    out->global_updates = c->h_ctrl->tally_gus;
+    out->launches = (uint64_t)replays * (uint64_t)c->launches_per_replay;
+    out->solve_ms = ms;
+    c->solved = status == PSN_OK;
+    if (status != PSN_OK) return fail(c, status, "solve did not converge");
+    return PSN_OK;
+}
+
+int psn_get_flow(psn_ctx *c, int32_t *flow) {
+    if (!c || !flow) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    int *d;
+    HIPCHK(c, hipMalloc((void **)&d, std::max<size_t>(1, (size_t)c->m2) * sizeof(int)));
+    hipLaunchKernelGGL(k_flow, dim3(kGrid), dim3(kBlock), 0, c->stream, c->g, d);
+    hipError_t e = hipMemcpyAsync(flow, d, (size_t)c->m2 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_get_flow", e);
+    return PSN_OK;
+}
+
+int psn_get_residual(psn_ctx *c, int32_t *cap) {
+    if (!c || !cap) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(cap, c->g.cap, (size_t)c->m2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSN_OK;
+}
+
+int psn_get_prices(psn_ctx *c, int64_t *price) {
+    if (!c || !price) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(price, c->g.price, (size_t)c->n * sizeof(i64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSN_OK;
+}
+
+int psn_get_costs(psn_ctx *c, int32_t *cost, int32_t *cap_orig) {
+    if (!c || (!cost && !cap_orig)) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (cost) HIPCHK(c, hipMemcpyAsync(cost, c->d_cost, (size_t)c->m2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (cap_orig) HIPCHK(c, hipMemcpyAsync(cap_orig, c->d_ocap, (size_t)c->m2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSN_OK;
+}
+
+static int run_placements(psn_ctx *c, const psn_layout *lay) {
+    if (!lay) return fail(c, PSN_EINVAL, "null layout");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    const int N = lay->n_machines, E = lay->n_classes, J = lay->n_jobs, P = lay->n_tasks, K = lay->k_slots;
+    if (N <= 0 || E <= 0 || J < 0 || P <= 0 || K <= 0 || (long long)1 + N + E + J + P != c->n)
+        return fail(c, PSN_EINVAL, "layout does not match the uploaded network");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->place_count != P || c->slot_stride != P || c->slot_classes != E) {
+        int rc;
+        if ((rc = dalloc(c, &c->d_place, (size_t)P)) != PSN_OK) return rc;
+        if ((rc = dalloc(c, &c->d_slot_machine, (size_t)E * (size_t)P)) != PSN_OK) return rc;
+        c->place_count = P; c->slot_stride = P; c->slot_classes = E;
+    }
+    hipLaunchKernelGGL(k_fill_i32, dim3(256), dim3(kBlock), 0, c->stream, c->d_place, -1, (long long)P);
+    hipLaunchKernelGGL(k_placements, dim3(E), dim3(kBlock), 0, c->stream, c->g, N, E, K, 1 + N + E + J, c->d_slot_machine, P, c->d_place);
+    HIPCHK(c, hipGetLastError());
+    return PSN_OK;
+}
+
+int psn_get_placements(psn_ctx *c, const psn_layout *lay, int32_t *task_to_machine) {
+    if (!c || !task_to_machine) return fail(c, PSN_EINVAL, "null argument");
+    int rc = run_placements(c, lay);
+    if (rc != PSN_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(task_to_machine, c->d_place, (size_t)lay->n_tasks * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSN_OK;
+}
+
+int psn_placements_device_ptr(psn_ctx *c, void **dptr, int64_t *count) {
+    if (!c || !dptr || !count) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->d_place) return fail(c, PSN_ESTATE, "no placements computed yet");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *dptr = c->d_place;
+    *count = c->place_count;
+    return PSN_OK;
+}
+
+}  // extern "C"

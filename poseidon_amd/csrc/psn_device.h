@@ -1,0 +1,92 @@
+// Shared host/device declarations of libpsn: device-resident graph view, control
+// block and kernel prototypes.  Included by the kernels and by the C-ABI host code.
+#ifndef PSN_DEVICE_H_
+#define PSN_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psn {
+
+typedef long long i64;
+
+constexpr int kBlock = 256;      // threads per workgroup (4 waves)
+constexpr int kGrid = 1024;      // workgroups per sweep launch: 16 waves per CU on 256 CUs
+constexpr unsigned kLowMax = 4;  // degree <= kLowMax: one lane per vertex
+constexpr unsigned kMedMax = 1024;  // degree <= kMedMax: one wave per vertex
+constexpr unsigned kWSeg = 512;  // arcs per wave work item of a high-degree vertex
+constexpr unsigned kQCap = 256;  // entries per per-wave LDS frontier staging queue
+constexpr int kClsLow = 0, kClsMed = 1, kClsHigh = 2;
+constexpr int kGuIters = 12;     // frontier expansions per replay (multiple of 3)
+constexpr int PSN_EINFEASIBLE_DEV = -4;
+
+// tally slots (per wave, summed at the end of a solve)
+enum { kTallyScans = 0, kTallyPushes, kTallyRelabels, kTallyVisits, kTallyGuScans, kTallyGuRelax,
+       kTallySat, kTallyRounds, kTallyGuIters, kTallyN };
+
+// Device-resident loop control.  Single-thread kernels (k_begin / k_mid / k_end) are the
+// only writers of the flags; sweep kernels read them and return at once when their
+// stage is off, which is what lets a fixed hipGraph be replayed until `done`.
+struct Ctrl {
+    i64 eps;
+    i64 dmax;
+    int eps_shift, alpha_log2;
+    int need_sat, need_gu, gu_active;
+    int sat_on, gu_on, gu_init_on, gu_apply_on, rounds_on;
+    int done, error;
+    unsigned epoch, gu_stamp_base;
+    unsigned list_cnt[2][4];
+    unsigned fr_cnt[3][4];
+    unsigned long long tally_refines, tally_gus;
+};
+
+// Plain-pointer view of one flow network in HBM (struct of arrays).
+//   static:  row[n+1] (u32 offsets), head/cost/rev/tail/ocap[m2], cls[n]
+//   dynamic: cap[m2] residual capacity, rcap[m2] = cap[rev[a]] (kept in step by every
+//            push so that the global update streams 4 B per arc instead of gathering),
+//            price/excess/cand/dist[n], fstamp[n]
+struct DevGraph {
+    int n;
+    unsigned m2;
+    i64 scale;  // S = n + 1
+    const unsigned *row;
+    const int *head, *cost, *rev, *tail, *ocap;
+    const unsigned char *cls;
+    int *cap, *rcap;
+    i64 *price, *excess, *cand, *dist;
+    unsigned *fstamp;
+    int *list_low[2], *list_med[2];
+    int2 *list_high[2];
+    int *fr_low[3], *fr_med[3];
+    int2 *fr_high[3];
+    unsigned long long *tally;
+    Ctrl *ctrl;
+};
+
+__global__ void k_push(DevGraph g, int k);
+__global__ void k_relabel_compact(DevGraph g, int k, int do_relabel);
+__global__ void k_saturate(DevGraph g);
+__global__ void k_gu_init(DevGraph g);
+__global__ void k_gu_expand(DevGraph g, int k);
+__global__ void k_gu_dmax(DevGraph g);
+__global__ void k_gu_apply(DevGraph g);
+__global__ void k_begin(DevGraph g);
+__global__ void k_mid(DevGraph g, int n_iters);
+__global__ void k_end(DevGraph g, int n_rounds);
+__global__ void k_reset(DevGraph g, const i64 *supply, int keep_flow);
+__global__ void k_mirror(DevGraph g, const i64 *supply, int recompute_excess);
+__global__ void k_excess_from_flow(DevGraph g);
+__global__ void k_total_cost(DevGraph g, i64 *out);
+__global__ void k_flow(DevGraph g, int *flow);
+__global__ void k_tally_sum(DevGraph g, unsigned long long *out, int nslots);
+__global__ void k_eval_costs(DevGraph g, int E, int N, int K, const i64 *cap_cpu, const i64 *cap_mem, const i64 *used_cpu,
+                             const i64 *used_mem, const i64 *req_cpu, const i64 *req_mem, const i64 *ec_arc_base, int *mcost,
+                             int *mocap);
+__global__ void k_placements(DevGraph g, int N, int E, int K, int v_task0, int *slot_machine, int slot_stride, int *place);
+__global__ void k_fill_i32(int *p, int v, long long n);
+__global__ void k_scatter_caps(DevGraph g, long long count, const i64 *idx, const int *ncap, int *mocap);
+__global__ void k_clamp_flow(DevGraph g);
+__global__ void k_scatter_supply(long long count, const int *vtx, const i64 *val, i64 *supply);
+
+}  // namespace psn
+#endif

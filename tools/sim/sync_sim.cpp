@@ -1,0 +1,161 @@
+// Design-study tool (not part of the product, not an oracle): a sequential model of the
+// bulk-synchronous cost-scaling push-relabel that the HIP kernels implement, used to count
+// rounds / arc scans for heuristic choices before spending GPU time.
+//   g++ -O2 -o /tmp/sync_sim tools/sim/sync_sim.cpp && /tmp/sync_sim /tmp/g1.bin [alpha] [gu_period] [sat_mode]
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <chrono>
+typedef int64_t i64;
+typedef int32_t i32;
+
+struct Graph {
+    i64 n, m2;
+    std::vector<i64> row, supply;
+    std::vector<i32> head, cap, cost, rev;
+};
+static bool load(const char *p, Graph &g) {
+    FILE *f = fopen(p, "rb");
+    if (!f) return false;
+    i64 h[2];
+    if (fread(h, 8, 2, f) != 2) return false;
+    g.n = h[0]; g.m2 = h[1];
+    g.row.resize(g.n + 1); g.head.resize(g.m2); g.cap.resize(g.m2); g.cost.resize(g.m2); g.rev.resize(g.m2); g.supply.resize(g.n);
+    bool ok = fread(g.row.data(), 8, g.n + 1, f) == (size_t)g.n + 1 && fread(g.head.data(), 4, g.m2, f) == (size_t)g.m2 &&
+              fread(g.cap.data(), 4, g.m2, f) == (size_t)g.m2 && fread(g.cost.data(), 4, g.m2, f) == (size_t)g.m2 &&
+              fread(g.rev.data(), 4, g.m2, f) == (size_t)g.m2 && fread(g.supply.data(), 8, g.n, f) == (size_t)g.n;
+    fclose(f);
+    return ok;
+}
+static inline i64 floordiv(i64 a, i64 b) { i64 q = a / b; if ((a % b) != 0 && a < 0) --q; return q; }
+
+struct Sim {
+    Graph &g;
+    i64 S;
+    std::vector<i64> price, excess, delta, cand, dist;
+    std::vector<i32> cap;
+    int alpha = 8, gu_period = 8, sat_mode = 1;
+    // stats
+    i64 rounds = 0, scans = 0, pushes = 0, relabels = 0, gu_iters = 0, gu_scans = 0, gus = 0, sat_scans = 0;
+    Sim(Graph &g_) : g(g_), S(g_.n + 1), price(g_.n, 0), excess(g_.supply), delta(g_.n, 0), cand(g_.n), dist(g_.n), cap(g_.cap) {}
+    inline i64 rc(i64 a, i32 u) const { return (i64)g.cost[a] * S + price[u] - price[g.head[a]]; }
+
+    void saturate(i64 eps) {
+        i64 thr = sat_mode ? -eps : 0;
+        for (i32 u = 0; u < g.n; ++u)
+            for (i64 a = g.row[u]; a < g.row[u + 1]; ++a) {
+                ++sat_scans;
+                if (cap[a] > 0 && rc(a, u) < thr) {
+                    i64 d = cap[a];
+                    cap[a] = 0; cap[g.rev[a]] += (i32)d;
+                    excess[u] -= d; excess[g.head[a]] += d;
+                }
+            }
+    }
+    void global_update(i64 eps) {
+        const i64 INF = INT64_MAX / 4;
+        ++gus;
+        std::vector<i32> fr, nx;
+        std::vector<char> innx(g.n, 0);
+        for (i32 v = 0; v < g.n; ++v) { if (excess[v] < 0) { dist[v] = 0; fr.push_back(v); } else dist[v] = INF; }
+        while (!fr.empty()) {
+            ++gu_iters;
+            nx.clear();
+            for (i32 v : fr) {
+                i64 dv = dist[v];
+                for (i64 a = g.row[v]; a < g.row[v + 1]; ++a) {
+                    ++gu_scans;
+                    i64 r = g.rev[a];
+                    if (cap[r] <= 0) continue;
+                    i32 u = g.head[a];
+                    i64 rcv = (i64)g.cost[r] * S + price[u] - price[v];
+                    i64 l = floordiv(rcv, eps) + 1;
+                    if (l < 0) l = 0;
+                    if (dv + l < dist[u]) { dist[u] = dv + l; if (!innx[u]) { innx[u] = 1; nx.push_back(u); } }
+                }
+            }
+            for (i32 u : nx) innx[u] = 0;
+            fr.swap(nx);
+        }
+        i64 dmax = 0;
+        for (i32 v = 0; v < g.n; ++v) if (dist[v] < INF) dmax = std::max(dmax, dist[v]);
+        for (i32 v = 0; v < g.n; ++v) price[v] -= eps * (dist[v] < INF ? dist[v] : dmax + 1);
+    }
+    void refine(i64 eps) {
+        i64 r0 = rounds, s0 = scans, p0 = pushes, l0 = relabels, gi0 = gu_iters, gs0 = gu_scans;
+        saturate(eps);
+        global_update(eps);
+        std::vector<i32> act;
+        i64 local_round = 0;
+        for (;;) {
+            act.clear();
+            for (i32 v = 0; v < g.n; ++v) if (excess[v] > 0) act.push_back(v);
+            if (act.empty()) break;
+            ++rounds; ++local_round;
+            // push phase: prices frozen, excess snapshot (arrivals go to delta)
+            for (i32 u : act) {
+                i64 e = excess[u], e0 = e;
+                i64 best = INT64_MIN;
+                i64 deg = g.row[u + 1] - g.row[u];
+                i64 off = deg ? (i64)(((uint64_t)u * 0x9E3779B97F4A7C15ULL + (uint64_t)rounds * 0xD1B54A32D192ED03ULL) >> 33) % deg : 0;
+                for (i64 k = 0; k < deg; ++k) {
+                    i64 a = g.row[u] + (off + k) % deg;
+                    ++scans;
+                    if (cap[a] <= 0) continue;
+                    i32 v = g.head[a];
+                    i64 key = price[v] - (i64)g.cost[a] * S;
+                    if (key > price[u] && e > 0) { // admissible
+                        i64 d = std::min<i64>(e, cap[a]);
+                        cap[a] -= (i32)d; cap[g.rev[a]] += (i32)d;
+                        e -= d; delta[v] += d; ++pushes;
+                        // reverse arc (v,u) became residual: candidate for v's relabel
+                        i64 kr = price[u] + (i64)g.cost[a] * S;
+                        if (kr > cand[v]) cand[v] = kr;
+                        if (cap[a] > 0 && key > best) best = key;
+                    } else if (key > best) best = key;
+                }
+                delta[u] -= (e0 - e);
+                if (best > cand[u]) cand[u] = best;
+            }
+            // relabel phase
+            for (i32 u : act) {
+                excess[u] += delta[u]; delta[u] = 0;
+            }
+            for (i32 v = 0; v < g.n; ++v) if (delta[v]) { excess[v] += delta[v]; delta[v] = 0; }
+            for (i32 u : act) {
+                if (excess[u] > 0 && cand[u] <= price[u] && cand[u] != INT64_MIN) { price[u] = cand[u] - eps; ++relabels; }
+            }
+            for (i32 v = 0; v < g.n; ++v) cand[v] = INT64_MIN;
+            if (gu_period > 0 && local_round % gu_period == 0) global_update(eps);
+        }
+        printf("  eps %-14ld rounds %-6ld scans %-12ld pushes %-9ld relabels %-9ld gu_iters %-5ld gu_scans %-11ld\n", (long)eps,
+               (long)(rounds - r0), (long)(scans - s0), (long)(pushes - p0), (long)(relabels - l0), (long)(gu_iters - gi0), (long)(gu_scans - gs0));
+    }
+    i64 solve() {
+        i64 eps = 1;
+        for (i64 a = 0; a < g.m2; ++a) if (cap[a] > 0) eps = std::max<i64>(eps, std::abs((i64)g.cost[a]) * S);
+        std::fill(cand.begin(), cand.end(), INT64_MIN);
+        do { eps = std::max<i64>(1, eps / alpha); refine(eps); } while (eps > 1);
+        i64 tc = 0;
+        for (i64 a = 0; a < g.m2; ++a) { i64 f = (i64)g.cap[a] - cap[a]; if (f > 0) tc += f * g.cost[a]; }
+        return tc;
+    }
+};
+
+int main(int argc, char **argv) {
+    Graph g;
+    if (argc < 2 || !load(argv[1], g)) { fprintf(stderr, "usage: sync_sim graph.bin [alpha] [gu_period] [sat_mode]\n"); return 1; }
+    Sim s(g);
+    if (argc > 2) s.alpha = atoi(argv[2]);
+    if (argc > 3) s.gu_period = atoi(argv[3]);
+    if (argc > 4) s.sat_mode = atoi(argv[4]);
+    auto t0 = std::chrono::steady_clock::now();
+    i64 tc = s.solve();
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    printf("cost %ld  rounds %ld scans %ld (%.1f x m2) pushes %ld relabels %ld | gus %ld gu_iters %ld gu_scans %ld (%.1f x m2) | sat_scans %ld | sim %.0f ms\n",
+           (long)tc, (long)s.rounds, (long)s.scans, (double)s.scans / g.m2, (long)s.pushes, (long)s.relabels, (long)s.gus, (long)s.gu_iters,
+           (long)s.gu_scans, (double)s.gu_scans / g.m2, (long)s.sat_scans, ms);
+    return 0;
+}
