@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/psn.h"
@@ -84,6 +85,7 @@ void free_graph_buffers(psn_ctx *c) {
 int enqueue_replay(psn_ctx *c, hipStream_t s) {
     const DevGraph &g = c->g;
     int launches = 0;
+    const int gv = std::max(1, std::min(kGrid, (g.n + kBlock - 1) / kBlock));  // vertex sweeps
 #define L(kern, grid, ...)                                                \
     do {                                                                  \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, __VA_ARGS__); \
@@ -91,15 +93,14 @@ int enqueue_replay(psn_ctx *c, hipStream_t s) {
     } while (0)
     hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, g); ++launches;
     L(k_saturate, kGrid, g);
-    L(k_gu_init, kGrid, g);
+    L(k_gu_init, gv, g);
     for (int k = 0; k < kGuIters; ++k) L(k_gu_expand, kGrid, g, k);
     hipLaunchKernelGGL(k_mid, dim3(1), dim3(1), 0, s, g, kGuIters); ++launches;
-    L(k_gu_dmax, kGrid, g);
-    L(k_gu_apply, kGrid, g);
-    L(k_relabel_compact, kGrid, g, 0, 0);
+    L(k_gu_apply, gv, g);
+    L(k_relabel_compact, gv, g, 0, 0);
     for (int k = 0; k < c->rounds; ++k) {
         L(k_push, kGrid, g, k);
-        L(k_relabel_compact, kGrid, g, k, 1);
+        L(k_relabel_compact, gv, g, k, 1);
     }
     hipLaunchKernelGGL(k_end, dim3(1), dim3(1), 0, s, g, c->rounds); ++launches;
 #undef L
@@ -250,27 +251,45 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
         if (deg > kMedMax) high_items += (deg + kWSeg - 1) / kWSeg;
     }
     c->high_items = high_items;
+    // hubs: the kMaxHubs highest-degree vertices among those split into several items
+    std::vector<int> hub_of((size_t)n, -1), hub_vertex((size_t)kMaxHubs, 0);
+    int nhubs = 0;
+    {
+        std::vector<std::pair<unsigned, int>> big;
+        for (int32_t v = 0; v < n; ++v)
+            if (cls[(size_t)v] == kClsHigh) big.emplace_back(row[(size_t)v + 1] - row[(size_t)v], v);
+        std::sort(big.begin(), big.end(), [](const std::pair<unsigned, int> &x, const std::pair<unsigned, int> &y) {
+            return x.first != y.first ? x.first > y.first : x.second < y.second;
+        });
+        for (size_t i = 0; i < big.size() && nhubs < kMaxHubs; ++i) {
+            hub_of[(size_t)big[i].second] = nhubs;
+            hub_vertex[(size_t)nhubs++] = big[i].second;
+        }
+    }
     // ---- allocate
     DevGraph &g = c->g;
     g = DevGraph{};
     g.n = n;
     g.m2 = (unsigned)m2;
     g.scale = (i64)n + 1;
-    unsigned *d_row; int *d_head, *d_rev, *d_tail; unsigned char *d_cls;
+    unsigned *d_row; int *d_head, *d_rev, *d_tail, *d_hub_of, *d_hub_vertex; unsigned char *d_cls;
     int rc;
 #define A(p, cnt) if ((rc = dalloc(c, &(p), (size_t)(cnt))) != PSN_OK) { free_graph_buffers(c); return rc; }
-    A(d_row, n + 1) A(d_head, m2) A(c->d_cost, m2) A(d_rev, m2) A(d_tail, m2) A(c->d_ocap, m2) A(d_cls, n)
+    A(d_row, n + 1) A(d_head, m2) A(c->d_cost, m2) A(d_rev, m2) A(d_tail, m2) A(c->d_ocap, m2) A(d_cls, n) A(d_hub_of, n) A(d_hub_vertex, kMaxHubs)
     A(g.cap, m2) A(g.rcap, m2) A(g.price, n) A(g.excess, n) A(g.cand, n) A(g.dist, n) A(g.fstamp, n)
     A(c->d_supply, n) A(c->d_scalar, 8)
-    for (int i = 0; i < 2; ++i) { A(g.list_low[i], n) A(g.list_med[i], n) A(g.list_high[i], high_items) }
-    for (int i = 0; i < 3; ++i) { A(g.fr_low[i], n) A(g.fr_med[i], n) A(g.fr_high[i], high_items) }
+    for (int i = 0; i < 2; ++i) { A(g.list_low[i], n) A(g.list_seg[i], (size_t)n + high_items) }
+    for (int i = 0; i < 3; ++i) { A(g.fr_low[i], n) A(g.fr_seg[i], (size_t)n + high_items) }
     c->tally_slots = kGrid * (kBlock / 64);
     A(g.tally, (size_t)c->tally_slots * kTallyN) A(c->d_tally_out, kTallyN) A(g.ctrl, 1)
 #undef A
     g.row = d_row; g.head = d_head; g.cost = c->d_cost; g.rev = d_rev; g.tail = d_tail; g.ocap = c->d_ocap; g.cls = d_cls;
+    g.hub_of = d_hub_of; g.hub_vertex = d_hub_vertex; g.nhubs = nhubs;
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(d_row, row.data(), sizeof(unsigned) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_cls, cls.data(), (size_t)n, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_hub_of, hub_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_hub_vertex, hub_vertex.data(), sizeof(int) * (size_t)kMaxHubs, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_tail, tail.data(), sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_head, head, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_cost, cost, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));

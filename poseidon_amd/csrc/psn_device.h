@@ -13,10 +13,12 @@ typedef long long i64;
 constexpr int kBlock = 256;      // threads per workgroup (4 waves)
 constexpr int kGrid = 1024;      // workgroups per sweep launch: 16 waves per CU on 256 CUs
 constexpr unsigned kLowMax = 4;  // degree <= kLowMax: one lane per vertex
-constexpr unsigned kMedMax = 1024;  // degree <= kMedMax: one wave per vertex
-constexpr unsigned kWSeg = 512;  // arcs per wave work item of a high-degree vertex
+constexpr unsigned kWSeg = 1024; // arcs per wave work item; larger vertices are split into several items
+constexpr unsigned kMedMax = kWSeg;  // degree <= kMedMax: the whole vertex is one wave item
 constexpr unsigned kQCap = 256;  // entries per per-wave LDS frontier staging queue
-constexpr int kClsLow = 0, kClsMed = 1, kClsHigh = 2;
+constexpr int kClsLow = 0, kClsMed = 1, kClsHigh = 2;  // vertex classes by degree
+constexpr int kClsSeg = 1;       // counter slot of the (vertex, segment) item lists (slot 0: lane list)
+constexpr int kMaxHubs = 128;    // highest-degree vertices whose atomics are pre-combined in LDS per workgroup
 constexpr int kGuIters = 12;     // frontier expansions per replay (multiple of 3)
 constexpr int PSN_EINFEASIBLE_DEV = -4;
 
@@ -41,7 +43,7 @@ struct Ctrl {
 };
 
 // Plain-pointer view of one flow network in HBM (struct of arrays).
-//   static:  row[n+1] (u32 offsets), head/cost/rev/tail/ocap[m2], cls[n]
+//   static:  row[n+1] (u32 offsets), head/cost/rev/tail/ocap[m2], cls[n], hub_of[n]
 //   dynamic: cap[m2] residual capacity, rcap[m2] = cap[rev[a]] (kept in step by every
 //            push so that the global update streams 4 B per arc instead of gathering),
 //            price/excess/cand/dist[n], fstamp[n]
@@ -52,13 +54,16 @@ struct DevGraph {
     const unsigned *row;
     const int *head, *cost, *rev, *tail, *ocap;
     const unsigned char *cls;
+    const int *hub_of;      // hub slot of a vertex, -1 for the rest
+    const int *hub_vertex;  // vertex of each hub slot
+    int nhubs;
     int *cap, *rcap;
     i64 *price, *excess, *cand, *dist;
     unsigned *fstamp;
-    int *list_low[2], *list_med[2];
-    int2 *list_high[2];
-    int *fr_low[3], *fr_med[3];
-    int2 *fr_high[3];
+    int *list_low[2];   // active vertices of degree <= kLowMax (one lane each)
+    int2 *list_seg[2];  // active (vertex, segment) wave items
+    int *fr_low[3];     // global-update frontier, same split, triple buffered
+    int2 *fr_seg[3];
     unsigned long long *tally;
     Ctrl *ctrl;
 };
@@ -68,7 +73,6 @@ __global__ void k_relabel_compact(DevGraph g, int k, int do_relabel);
 __global__ void k_saturate(DevGraph g);
 __global__ void k_gu_init(DevGraph g);
 __global__ void k_gu_expand(DevGraph g, int k);
-__global__ void k_gu_dmax(DevGraph g);
 __global__ void k_gu_apply(DevGraph g);
 __global__ void k_begin(DevGraph g);
 __global__ void k_mid(DevGraph g, int n_iters);

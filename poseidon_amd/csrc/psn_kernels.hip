@@ -1,8 +1,8 @@
 // libpsn device code: cost-scaling push-relabel min-cost flow for gfx950 (MI355X).
 //
-// Everything here is wave-centric (64 lanes): a work item is a vertex (one lane for
-// degree <= 4, one wave up to degree 1024) or a 512-arc segment of a high-degree
-// vertex handled by one wave.  No kernel needs a workgroup barrier.
+// Everything here is wave-centric (64 lanes): a work item is a vertex of degree <= 4
+// (one lane) or a segment of up to 1024 arcs of a larger vertex (one wave, 8 arcs per
+// lane per step).  The sweep kernels need no workgroup barrier.
 //
 // The algorithm is bulk-synchronous so that the result does not depend on timing:
 //   push phase     prices frozen; every active vertex pushes on admissible arcs
@@ -62,52 +62,128 @@ __device__ __forceinline__ unsigned mix32(unsigned a, unsigned b) {
     return (unsigned)z;
 }
 
-// Per-thread work counters; folded into a per-block slot (no atomics: block b owns
-// slot b in every launch, and launches on one stream are ordered).
+// Per-wave work counters; folded into a per-wave slot (no atomics: wave w of block b owns
+// slot (b, w) in every launch, and launches on one stream are ordered).  A wave that
+// counted nothing skips the fold.
 struct Tally { unsigned long long c[kTallyN]; __device__ Tally() { for (int i = 0; i < kTallyN; ++i) c[i] = 0; } };
+template <int... Idx>
 __device__ __forceinline__ void tally_flush(const DevGraph &g, Tally &t) {
-    bool any = false;
-#pragma unroll
-    for (int i = 0; i < kTallyN; ++i) { t.c[i] = wave_sum_u64(t.c[i]); any |= t.c[i] != 0; }
-    if (lane_id() == 0 && any) {
+    unsigned long long any = 0;
+    ((any |= t.c[Idx]), ...);
+    if (!__ballot(any != 0)) return;
+    ((t.c[Idx] = wave_sum_u64(t.c[Idx])), ...);
+    if (lane_id() == 0) {
         unsigned long long *slot = g.tally + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kTallyN;
-#pragma unroll
-        for (int i = 0; i < kTallyN; ++i) if (t.c[i]) slot[i] += t.c[i];
+        ((slot[Idx] += t.c[Idx]), ...);
     }
 }
 
+__device__ __forceinline__ unsigned nseg_of(const DevGraph &g, int v) {
+    return (g.row[v + 1] - g.row[v] + kWSeg - 1) / kWSeg;
+}
+
 // ------------------------------------------------------- active-list compaction (K4)
-// Appends the vertices flagged by `take` to the class lists: one ballot per class,
-// one atomic per wave per non-empty class, slots by popcount prefix.
-__device__ __forceinline__ void wave_append(const DevGraph &g, unsigned *cnt, int *lowl, int *medl, int2 *highl,
-                                            bool take, int v, int cls) {
+// Appends the vertices flagged by `take` to the work lists: one ballot per list, one
+// atomic per wave per non-empty list, slots by popcount prefix.  Vertices of degree
+// <= kLowMax go to the lane list; all others become (vertex, segment) wave items.
+__device__ __forceinline__ void wave_append(const DevGraph &g, unsigned *cnt, int *lowl, int2 *segl, bool take, int v, int cls) {
     const unsigned long long lt = lanemask_lt();
     unsigned long long m = __ballot(take && cls == kClsLow);
     if (m) {
+        const int leader = __ffsll((long long)m) - 1;
         unsigned base = 0;
-        if (lane_id() == __ffsll((long long)m) - 1) base = aadd32(&cnt[kClsLow], (unsigned)__popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (lane_id() == leader) base = aadd32(&cnt[kClsLow], (unsigned)__popcll(m));
+        base = __shfl(base, leader);
         if (take && cls == kClsLow) lowl[base + __popcll(m & lt)] = v;
     }
     m = __ballot(take && cls == kClsMed);
     if (m) {
+        const int leader = __ffsll((long long)m) - 1;
         unsigned base = 0;
-        if (lane_id() == __ffsll((long long)m) - 1) base = aadd32(&cnt[kClsMed], (unsigned)__popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1);
-        if (take && cls == kClsMed) medl[base + __popcll(m & lt)] = v;
+        if (lane_id() == leader) base = aadd32(&cnt[kClsSeg], (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        if (take && cls == kClsMed) segl[base + __popcll(m & lt)] = make_int2(v, 0);
     }
     if (take && cls == kClsHigh) {  // rare: a handful of vertices own most arcs
-        unsigned deg = g.row[v + 1] - g.row[v];
-        unsigned nseg = (deg + kWSeg - 1) / kWSeg;
-        unsigned base = aadd32(&cnt[kClsHigh], nseg);
-        for (unsigned s = 0; s < nseg; ++s) highl[base + s] = make_int2(v, (int)s);
+        const unsigned nseg = nseg_of(g, v);
+        const unsigned base = aadd32(&cnt[kClsSeg], nseg);
+        for (unsigned s = 0; s < nseg; ++s) segl[base + s] = make_int2(v, (int)s);
+    }
+}
+
+// Same as wave_append with one atomic per workgroup per list: used by the vertex sweeps,
+// where every wave would otherwise hit the same two counters.  Uniform call sites only.
+__device__ __forceinline__ void block_append(const DevGraph &g, unsigned *cnt, int *lowl, int2 *segl, bool take, int v, int cls,
+                                             unsigned (*lds)[kBlock / 64 + 1]) {
+    const unsigned long long lt = lanemask_lt();
+    const unsigned long long mlow = __ballot(take && cls == kClsLow);
+    const unsigned long long mseg = __ballot(take && cls == kClsMed);
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) { lds[0][w] = (unsigned)__popcll(mlow); lds[1][w] = (unsigned)__popcll(mseg); }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned tot = 0;
+        for (int i = 0; i < kBlock / 64; ++i) tot += lds[threadIdx.x][i];
+        lds[threadIdx.x][kBlock / 64] = tot ? aadd32(&cnt[threadIdx.x == 0 ? kClsLow : kClsSeg], tot) : 0u;
+    }
+    __syncthreads();
+    if (take && cls != kClsHigh) {
+        const int c = cls == kClsLow ? 0 : 1;
+        unsigned pos = lds[c][kBlock / 64];
+        for (int i = 0; i < w; ++i) pos += lds[c][i];
+        if (c == 0) lowl[pos + __popcll(mlow & lt)] = v;
+        else segl[pos + __popcll(mseg & lt)] = make_int2(v, 0);
+    }
+    if (take && cls == kClsHigh) {
+        const unsigned nseg = nseg_of(g, v);
+        const unsigned base = aadd32(&cnt[kClsSeg], nseg);
+        for (unsigned s = 0; s < nseg; ++s) segl[base + s] = make_int2(v, (int)s);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ hub accumulators
+// A few vertices (the sink, the task classes) receive most pushes and relaxations; their
+// same-address atomics would serialise at the memory side.  Each workgroup combines what
+// it sends to a hub in LDS and issues one global atomic per hub at the end of the kernel.
+struct HubAcc { i64 *add; i64 *ext; };  // LDS, kMaxHubs entries each: sum, and max (push) or min (distances)
+__device__ __forceinline__ void hub_init(const HubAcc &hb, i64 ext_init) {
+    for (int i = threadIdx.x; i < kMaxHubs; i += kBlock) { hb.add[i] = 0; hb.ext[i] = ext_init; }
+    __syncthreads();
+}
+__device__ __forceinline__ void lds_add(i64 *p, i64 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_max(i64 *p, i64 v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_min(i64 *p, i64 v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void excess_add(const DevGraph &g, const HubAcc &hb, int v, i64 d) {
+    const int h = g.hub_of[v];
+    if (h >= 0) lds_add(&hb.add[h], d); else aadd64(&g.excess[v], d);
+}
+// end of a push/saturate kernel: one atomic per hub touched by this workgroup
+__device__ __forceinline__ void hub_flush_push(const DevGraph &g, const HubAcc &hb) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.nhubs; i += kBlock) {
+        const int v = g.hub_vertex[i];
+        if (hb.add[i]) aadd64(&g.excess[v], hb.add[i]);
+        if (hb.ext[i] > kNegInf) amax64(&g.cand[v], hb.ext[i]);
+    }
+}
+
+// Eight consecutive int32 per lane, two 16-byte loads when fully inside [.., r1).
+__device__ __forceinline__ void load8(const int *p, unsigned a0, unsigned r1, int (&x)[8]) {
+    if (a0 + 7 < r1) {
+        const int4u lo = *reinterpret_cast<const int4u *>(p + a0);
+        const int4u hi = *reinterpret_cast<const int4u *>(p + a0 + 4);
+        x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = a0 + j < r1 ? p[a0 + j] : 0;
     }
 }
 
 // --------------------------------------------------------------------------- pushes
 // One unit of push bookkeeping: the caller owns arc a (tail u); r = rev[a] is only
 // written here because (v,u) cannot be admissible while (u,v) is.
-__device__ __forceinline__ void do_push(const DevGraph &g, unsigned a, int v, int cap_before, i64 d, i64 pu, i64 cS) {
+__device__ __forceinline__ void do_push(const DevGraph &g, const HubAcc &hb, unsigned a, int v, int cap_before, i64 d, i64 pu, i64 cS) {
     const int r = g.rev[a];
     const int na = cap_before - (int)d;
     const int nr = g.cap[r] + (int)d;
@@ -115,12 +191,14 @@ __device__ __forceinline__ void do_push(const DevGraph &g, unsigned a, int v, in
     g.cap[r] = nr;
     g.rcap[a] = nr;
     g.rcap[r] = na;
-    aadd64(&g.excess[v], d);
-    amax64(&g.cand[v], pu + cS);  // key of the new residual arc (v,u): price[u] - cost(v,u)
+    const int h = g.hub_of[v];
+    const i64 key = pu + cS;  // key of the new residual arc (v,u): price[u] - cost(v,u)
+    if (h >= 0) { lds_add(&hb.add[h], d); lds_max(&hb.ext[h], key); }
+    else { aadd64(&g.excess[v], d); amax64(&g.cand[v], key); }
 }
 
 // Low-degree vertex: one lane walks its arcs.
-__device__ __forceinline__ void push_low(const DevGraph &g, int u, i64 S, Tally &t) {
+__device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, int u, i64 S, Tally &t) {
     const unsigned r0 = g.row[u], r1 = g.row[u + 1];
     const i64 pu = g.price[u];
     const i64 e0 = g.excess[u];
@@ -135,7 +213,7 @@ __device__ __forceinline__ void push_low(const DevGraph &g, int u, i64 S, Tally 
         const i64 key = g.price[v] - cS;
         if (key > pu && e > 0) {
             i64 d = e < cp ? e : cp;
-            do_push(g, a, v, cp, d, pu, cS);
+            do_push(g, hb, a, v, cp, d, pu, cS);
             e -= d; cp -= (int)d;
             t.c[kTallyPushes]++;
         }
@@ -145,144 +223,116 @@ __device__ __forceinline__ void push_low(const DevGraph &g, int u, i64 S, Tally 
     if (e != e0) aadd64(&g.excess[u], e - e0);
 }
 
-// Medium-degree vertex: one wave, 64 arcs per step, chunk order rotated per round.
-__device__ __forceinline__ void push_med(const DevGraph &g, int u, i64 S, unsigned salt, Tally &t) {
-    const int lane = lane_id();
-    const unsigned r0 = g.row[u], r1 = g.row[u + 1];
-    const unsigned nch = (r1 - r0 + 63) >> 6;
-    const i64 pu = g.price[u];
-    const i64 e0 = g.excess[u];
-    i64 e = e0, best = kNegInf;
-    bool incomplete = false;
-    if (lane == 0) t.c[kTallyVisits]++;
-    unsigned c = nch > 1 ? mix32((unsigned)u, salt) % nch : 0;
-    for (unsigned ci = 0; ci < nch; ++ci) {
-        const unsigned a = r0 + (c << 6) + lane;
-        if (++c == nch) c = 0;
-        const bool valid = a < r1;
-        int cp = valid ? g.cap[a] : 0;
-        if (valid) t.c[kTallyScans]++;
-        int v = 0; i64 cS = 0, key = kNegInf;
-        if (cp > 0) { v = g.head[a]; cS = (i64)g.cost[a] * S; key = g.price[v] - cS; }
-        const bool adm = cp > 0 && key > pu;
-        if (__ballot(adm)) {
-            const i64 want = adm ? cp : 0;
-            const i64 incl = wave_incl_scan(want);
-            const i64 total = __shfl(incl, 63);
-            i64 give = e - (incl - want);
-            give = give < 0 ? 0 : (give > want ? want : give);
-            if (give > 0) { do_push(g, a, v, cp, give, pu, cS); cp -= (int)give; t.c[kTallyPushes]++; }
-            e -= total < e ? total : e;
-        }
-        if (cp > 0 && key > best) best = key;
-        if (e == 0 && ci + 1 < nch) { incomplete = true; break; }
-    }
-    best = wave_max(best);
-    if (lane == 0) {
-        if (incomplete) best = kInf;  // arcs not looked at: no relabel this round
-        if (best > kNegInf) amax64(&g.cand[u], best);
-        if (e != e0) aadd64(&g.excess[u], e - e0);
-    }
-}
-
-// High-degree vertex, one 512-arc segment per wave.  Several waves work on one vertex,
-// so each claims what it wants to push from excess[u] and hands back what it cannot use.
-__device__ __forceinline__ void push_high(const DevGraph &g, int u, unsigned seg, i64 S, Tally &t) {
+// One wave item: up to kWSeg arcs of vertex u, 512 per step (8 per lane, coalesced 16-byte
+// loads).  A vertex that fits one item keeps its excess in a register; a vertex split
+// over several items has its waves claim what they want to push from excess[u] and hand
+// back what was not granted.  `rot` permutes which lane owns which 8 arcs, so that the
+// prefix order (= who gets the excess first) changes from round to round.
+__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int u, unsigned seg, bool solo, i64 S, unsigned rot, Tally &t) {
     const int lane = lane_id();
     const unsigned r0 = g.row[u] + seg * kWSeg;
     const unsigned r1 = min(g.row[u + 1], r0 + kWSeg);
     const i64 pu = g.price[u];
     if (lane == 0) t.c[kTallyVisits]++;
-    i64 avail = __hip_atomic_load(&g.excess[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (avail <= 0) {  // drained by the other segments: this one stays unscanned
+    i64 e0 = __hip_atomic_load(&g.excess[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    e0 = __shfl(e0, 0);
+    if (e0 <= 0) {  // drained by the vertex's other items: this one stays unscanned
         if (lane == 0) amax64(&g.cand[u], kInf);
         return;
     }
-    i64 best = kNegInf;
-    for (unsigned h = 0; h < kWSeg; h += 256) {
-        const unsigned a0 = r0 + h + lane * 4;
-        int cp[4], hd[4], cs[4];
-        if (a0 + 3 < r1) {
-            int4u x = *reinterpret_cast<const int4u *>(g.cap + a0);
-            int4u y = *reinterpret_cast<const int4u *>(g.head + a0);
-            int4u z = *reinterpret_cast<const int4u *>(g.cost + a0);
-            cp[0] = x.x; cp[1] = x.y; cp[2] = x.z; cp[3] = x.w;
-            hd[0] = y.x; hd[1] = y.y; hd[2] = y.z; hd[3] = y.w;
-            cs[0] = z.x; cs[1] = z.y; cs[2] = z.z; cs[3] = z.w;
-            t.c[kTallyScans] += 4;
-        } else {
+    i64 e = e0, best = kNegInf;
+    bool incomplete = false;
+    const unsigned plane = (unsigned)(lane + rot) & 63u;
+    for (unsigned h = r0; h < r1; h += 512) {
+        const unsigned a0 = h + plane * 8;
+        int cp[8], hd[8], cs[8];
+        load8(g.cap, a0, r1, cp);
+        bool anyc = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = a0 + j < r1;
-                cp[j] = ok ? g.cap[a0 + j] : 0;
-                hd[j] = ok ? g.head[a0 + j] : 0;
-                cs[j] = ok ? g.cost[a0 + j] : 0;
-                if (ok) t.c[kTallyScans]++;
-            }
-        }
-        i64 key[4], want = 0;
+        for (int j = 0; j < 8; ++j) anyc |= cp[j] > 0;
+        if (a0 < r1) t.c[kTallyScans] += min(8u, r1 - a0);
+        if (anyc) { load8(g.head, a0, r1, hd); load8(g.cost, a0, r1, cs); }
+        i64 key[8], want = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            key[j] = cp[j] > 0 ? g.price[hd[j]] - (i64)cs[j] * S : kNegInf;
-            if (cp[j] > 0 && key[j] > pu) want += cp[j];
+        for (int j = 0; j < 8; ++j) {
+            key[j] = (anyc && cp[j] > 0) ? g.price[hd[j]] - (i64)cs[j] * S : kNegInf;
+            if (key[j] > pu) want += cp[j];
         }
         if (__ballot(want > 0)) {
             const i64 incl = wave_incl_scan(want);
             const i64 total = __shfl(incl, 63);
-            i64 granted = 0;
-            if (lane == 0) {
-                const i64 old = aadd64(&g.excess[u], -total);
-                granted = old <= 0 ? 0 : (old < total ? old : total);
-                if (granted < total) aadd64(&g.excess[u], total - granted);
-            }
-            granted = __shfl(granted, 0);
-            i64 mine = granted - (incl - want);  // what this lane may push
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (cp[j] > 0 && key[j] > pu && mine > 0) {
-                    const i64 d = mine < cp[j] ? mine : cp[j];
-                    do_push(g, a0 + j, hd[j], cp[j], d, pu, (i64)cs[j] * S);
-                    cp[j] -= (int)d; mine -= d;
-                    t.c[kTallyPushes]++;
+            i64 granted;
+            if (solo) {
+                granted = total < e ? total : e;
+                e -= granted;
+            } else {
+                granted = 0;
+                if (lane == 0) {
+                    const i64 old = aadd64(&g.excess[u], -total);
+                    granted = old <= 0 ? 0 : (old < total ? old : total);
+                    if (granted < total) aadd64(&g.excess[u], total - granted);
                 }
+                granted = __shfl(granted, 0);
+            }
+            i64 mine = granted - (incl - want);  // what this lane may push
+            if (mine > 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (key[j] > pu && mine > 0) {
+                        const i64 d = mine < cp[j] ? mine : cp[j];
+                        do_push(g, hb, a0 + j, hd[j], cp[j], d, pu, (i64)cs[j] * S);
+                        cp[j] -= (int)d; mine -= d;
+                        t.c[kTallyPushes]++;
+                    }
+                }
+            }
+            if (granted < total || (solo && e == 0)) {  // out of excess
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (cp[j] > 0 && key[j] > best) best = key[j];
+                if (h + 512 < r1) incomplete = true;
+                break;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (cp[j] > 0 && key[j] > best) best = key[j];
-        if (r0 + h + 256 >= r1) break;
+        for (int j = 0; j < 8; ++j) if (cp[j] > 0 && key[j] > best) best = key[j];
     }
     best = wave_max(best);
-    if (lane == 0 && best > kNegInf) amax64(&g.cand[u], best);
+    if (lane == 0) {
+        if (incomplete) best = kInf;  // arcs not looked at: no relabel this round
+        if (best > kNegInf) amax64(&g.cand[u], best);
+        if (solo && e != e0) aadd64(&g.excess[u], e - e0);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
     Ctrl *ct = g.ctrl;
     if (!ct->rounds_on) return;
     const unsigned *cnt = ct->list_cnt[k & 1];
-    const unsigned nlow = cnt[kClsLow], nmed = cnt[kClsMed], nhigh = cnt[kClsHigh];
+    const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg];
     if (blockIdx.x == 0 && threadIdx.x < 4) ct->list_cnt[(k + 1) & 1][threadIdx.x] = 0;
-    if (nlow + nmed + nhigh == 0) return;
+    if (nlow + nseg == 0) return;
+    __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
+    const HubAcc hb{s_add, s_max};
+    hub_init(hb, kNegInf);
     const i64 S = g.scale;
     const unsigned salt = ct->epoch * 64u + (unsigned)k;
     const int *lowl = g.list_low[k & 1];
-    const int *medl = g.list_med[k & 1];
-    const int2 *highl = g.list_high[k & 1];
+    const int2 *segl = g.list_seg[k & 1];
     const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
-    // segments of high-degree vertices first (largest items), start rotated per round so
-    // that vertices sharing neighbours do not all begin at the same ones
-    for (unsigned i = wave; i < nhigh; i += nwaves) {
-        const int2 it = highl[i];
-        const unsigned deg = g.row[it.x + 1] - g.row[it.x];
-        const unsigned nseg = (deg + kWSeg - 1) / kWSeg;
-        const unsigned seg = ((unsigned)it.y + mix32((unsigned)it.x, salt)) % nseg;
-        push_high(g, it.x, seg, S, t);
+    for (unsigned i = wave; i < nseg; i += nwaves) {
+        const int2 it = segl[i];
+        const unsigned ns = nseg_of(g, it.x);
+        const unsigned h = mix32((unsigned)it.x, salt);
+        // start segment rotated per round so that vertices sharing neighbours do not all
+        // begin at the same ones
+        push_item(g, hb, it.x, ns > 1 ? ((unsigned)it.y + h) % ns : 0u, ns == 1, S, h >> 16, t);
     }
-    for (unsigned i = wave; i < nmed; i += nwaves) push_med(g, medl[i], S, salt, t);
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, lowl[i], S, t);
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, hb, lowl[i], S, t);
+    hub_flush_push(g, hb);
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyRounds]++;
-    tally_flush(g, t);
+    tally_flush<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds>(g, t);
 }
 
 // Relabel (optional) + rebuild of the active lists for the next round: one sweep over
@@ -294,11 +344,12 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
     const int dst = do_relabel ? (k + 1) & 1 : 0;
     if (do_relabel) {
         const unsigned *cnt = ct->list_cnt[k & 1];
-        if (cnt[kClsLow] + cnt[kClsMed] + cnt[kClsHigh] == 0) return;  // nothing was active
+        if (cnt[kClsLow] + cnt[kClsSeg] == 0) return;  // nothing was active
     }
     const i64 eps = ct->eps;
     Tally t;
-    const int nround = (g.n + 63) & ~63;
+    __shared__ unsigned s_app[2][kBlock / 64 + 1];
+    const int nround = (g.n + kBlock - 1) / kBlock * kBlock;
     for (int v = blockIdx.x * kBlock + threadIdx.x; v < nround; v += gridDim.x * kBlock) {
         bool act = false;
         int cls = 0;
@@ -314,35 +365,67 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
             if (c != nc) g.cand[v] = nc;
             cls = g.cls[v];
         }
-        wave_append(g, ct->list_cnt[dst], g.list_low[dst], g.list_med[dst], g.list_high[dst], act, v, cls);
+        block_append(g, ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, s_app);
     }
-    tally_flush(g, t);
+    tally_flush<kTallyRelabels>(g, t);
 }
 
 // ------------------------------------------------------------- per-phase saturation
 // refine(eps) starts from an eps-optimal pseudoflow: every residual arc whose reduced
-// cost is below -eps is saturated.  One thread per arc; only the thread of arc a writes
-// cap[a] and cap[rev[a]] (the reverse has reduced cost > eps and is left alone).
+// cost is below -eps is saturated.  Four consecutive arcs per thread; only the thread of
+// arc a writes cap[a] and cap[rev[a]] (the reverse has reduced cost > eps and is left alone).
 __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) {
     Ctrl *ct = g.ctrl;
     if (!ct->sat_on) return;
     const i64 eps = ct->eps, S = g.scale;
     Tally t;
-    for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) {
-        const int cp = g.cap[a];
-        t.c[kTallySat]++;
-        if (cp <= 0) continue;
-        const int u = g.tail[a], v = g.head[a];
-        const i64 rc = (i64)g.cost[a] * S + g.price[u] - g.price[v];
-        if (rc < -eps) {
-            const int r = g.rev[a];
-            const int nr = g.cap[r] + cp;
-            g.cap[a] = 0; g.cap[r] = nr; g.rcap[a] = nr; g.rcap[r] = 0;
-            aadd64(&g.excess[u], -(i64)cp);
-            aadd64(&g.excess[v], (i64)cp);
+    __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
+    const HubAcc hb{s_add, s_max};
+    hub_init(hb, kNegInf);
+    const unsigned nquad = (g.m2 + 3) / 4;
+    for (unsigned q = blockIdx.x * kBlock + threadIdx.x; q < nquad; q += gridDim.x * kBlock) {
+        const unsigned a0 = q * 4;
+        int cp[4], tl[4], hd[4], cs[4];
+        if (a0 + 3 < g.m2) {
+            const int4u x = *reinterpret_cast<const int4u *>(g.cap + a0);
+            cp[0] = x.x; cp[1] = x.y; cp[2] = x.z; cp[3] = x.w;
+            t.c[kTallySat] += 4;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cp[j] = a0 + j < g.m2 ? g.cap[a0 + j] : 0; if (a0 + j < g.m2) t.c[kTallySat]++; }
+        }
+        if ((cp[0] | cp[1] | cp[2] | cp[3]) == 0) continue;  // capacities are never negative
+        if (a0 + 3 < g.m2) {
+            const int4u y = *reinterpret_cast<const int4u *>(g.tail + a0);
+            const int4u z = *reinterpret_cast<const int4u *>(g.head + a0);
+            const int4u w = *reinterpret_cast<const int4u *>(g.cost + a0);
+            tl[0] = y.x; tl[1] = y.y; tl[2] = y.z; tl[3] = y.w;
+            hd[0] = z.x; hd[1] = z.y; hd[2] = z.z; hd[3] = z.w;
+            cs[0] = w.x; cs[1] = w.y; cs[2] = w.z; cs[3] = w.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = a0 + j < g.m2;
+                tl[j] = ok ? g.tail[a0 + j] : 0; hd[j] = ok ? g.head[a0 + j] : 0; cs[j] = ok ? g.cost[a0 + j] : 0;
+            }
+        }
+        i64 rc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rc[j] = cp[j] > 0 ? (i64)cs[j] * S + g.price[tl[j]] - g.price[hd[j]] : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (cp[j] > 0 && rc[j] < -eps) {
+                const unsigned a = a0 + j;
+                const int r = g.rev[a];
+                const int nr = g.cap[r] + cp[j];
+                g.cap[a] = 0; g.cap[r] = nr; g.rcap[a] = nr; g.rcap[r] = 0;
+                excess_add(g, hb, tl[j], -(i64)cp[j]);
+                excess_add(g, hb, hd[j], (i64)cp[j]);
+            }
         }
     }
-    tally_flush(g, t);
+    hub_flush_push(g, hb);
+    tally_flush<kTallySat>(g, t);
 }
 
 // ------------------------------------------------------- global price update (K3)
@@ -351,21 +434,23 @@ __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) {
 // price[v] -= eps*dist[v].  Newly improved vertices are staged in a per-wave LDS queue
 // and flushed to the global frontier in coalesced bursts with one atomic per burst.
 struct WaveQ {
-    int *low, *med;       // LDS staging, kQCap entries each
-    unsigned nlow, nmed;  // wave-uniform fill counts
+    int *low;             // LDS staging, kQCap vertex ids
+    int2 *seg;            // LDS staging, kQCap (vertex, segment) items
+    unsigned nlow, nseg;  // wave-uniform fill counts
 };
-__device__ __forceinline__ void waveq_flush_one(int *q, unsigned &n, unsigned *cnt, int *dst) {
+template <typename T>
+__device__ __forceinline__ void waveq_flush_one(T *q, unsigned &n, unsigned *cnt, T *dst) {
     if (n == 0) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     unsigned base = 0;
     if (lane_id() == 0) base = aadd32(cnt, n);
     base = __shfl(base, 0);
     for (unsigned i = lane_id(); i < n; i += 64) dst[base + i] = q[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     n = 0;
 }
-__device__ __forceinline__ void waveq_push(const DevGraph &g, WaveQ &q, unsigned *cnt, int *lowl, int *medl, int2 *highl,
-                                           bool take, int v) {
-    int cls = take ? g.cls[v] : 0;
+__device__ __forceinline__ void waveq_push(const DevGraph &g, WaveQ &q, unsigned *cnt, int *lowl, int2 *segl, bool take, int v) {
+    const int cls = take ? g.cls[v] : 0;
     const unsigned long long lt = lanemask_lt();
     unsigned long long m = __ballot(take && cls == kClsLow);
     if (m) {
@@ -375,32 +460,35 @@ __device__ __forceinline__ void waveq_push(const DevGraph &g, WaveQ &q, unsigned
     }
     m = __ballot(take && cls == kClsMed);
     if (m) {
-        if (take && cls == kClsMed) q.med[q.nmed + __popcll(m & lt)] = v;
-        q.nmed += (unsigned)__popcll(m);
-        if (q.nmed > kQCap - 64) waveq_flush_one(q.med, q.nmed, &cnt[kClsMed], medl);
+        if (take && cls == kClsMed) q.seg[q.nseg + __popcll(m & lt)] = make_int2(v, 0);
+        q.nseg += (unsigned)__popcll(m);
+        if (q.nseg > kQCap - 64) waveq_flush_one(q.seg, q.nseg, &cnt[kClsSeg], segl);
     }
     if (take && cls == kClsHigh) {
-        unsigned deg = g.row[v + 1] - g.row[v];
-        unsigned nseg = (deg + kWSeg - 1) / kWSeg;
-        unsigned base = aadd32(&cnt[kClsHigh], nseg);
-        for (unsigned s = 0; s < nseg; ++s) highl[base + s] = make_int2(v, (int)s);
+        const unsigned nseg = nseg_of(g, v);
+        const unsigned base = aadd32(&cnt[kClsSeg], nseg);
+        for (unsigned s = 0; s < nseg; ++s) segl[base + s] = make_int2(v, (int)s);
     }
 }
 
-// Relax the tail of reversed arc a = (v,u): residual arc (u,v) has capacity rcap[a].
-__device__ __forceinline__ bool gu_relax(const DevGraph &g, unsigned a, i64 dv, i64 pv, i64 S, int sh, unsigned stamp,
-                                         int &u_out, Tally &t) {
-    const int u = g.head[a];
-    const i64 rc = -(i64)g.cost[a] * S + g.price[u] - pv;
-    i64 l = (rc >> sh) + 1;
-    if (l < 0) l = 0;
-    const i64 nd = dv + l;
-    if (nd >= g.dist[u]) return false;
+// Distances are lowered by atomics during the sweep, so pre-checks read them past the
+// (non-coherent) vector L1.
+__device__ __forceinline__ i64 ld_dist(const DevGraph &g, int u) {
+    return __hip_atomic_load(&g.dist[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Try dist[u] = nd; true if this lane is the one that must queue u for the next iteration.
+__device__ __forceinline__ bool gu_commit_global(const DevGraph &g, int u, i64 nd, unsigned stamp, i64 &wmax, Tally &t) {
     const i64 old = amin64(&g.dist[u], nd);
     if (nd >= old) return false;
     t.c[kTallyGuRelax]++;
-    u_out = u;
+    if (nd > wmax) wmax = nd;
     return axchg32(&g.fstamp[u], stamp) != stamp;  // first improver in this iteration queues u
+}
+// Hubs are only lowered in LDS here; the workgroup commits them once at the end.
+__device__ __forceinline__ bool gu_commit(const DevGraph &g, i64 *hub_min, int u, i64 nd, unsigned stamp, i64 &wmax, Tally &t) {
+    const int h = g.hub_of[u];
+    if (h >= 0) { lds_min(&hub_min[h], nd); return false; }
+    return gu_commit_global(g, u, nd, stamp, wmax, t);
 }
 
 __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
@@ -408,17 +496,21 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
     if (!ct->gu_on) return;
     const int src = k % 3, dst = (k + 1) % 3, clr = (k + 2) % 3;
     const unsigned *cnt = ct->fr_cnt[src];
-    const unsigned nlow = cnt[kClsLow], nmed = cnt[kClsMed], nhigh = cnt[kClsHigh];
+    const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg];
     if (blockIdx.x == 0 && threadIdx.x < 4) ct->fr_cnt[clr][threadIdx.x] = 0;
-    if (nlow + nmed + nhigh == 0) return;
-    __shared__ int lds_q[(kBlock / 64) * 2 * kQCap];
+    if (nlow + nseg == 0) return;
+    __shared__ int lds_low[(kBlock / 64) * kQCap];
+    __shared__ int2 lds_seg[(kBlock / 64) * kQCap];
+    __shared__ i64 s_hmin[kMaxHubs];
+    for (int i = threadIdx.x; i < kMaxHubs; i += kBlock) s_hmin[i] = kDistInf;
+    __syncthreads();
     WaveQ q;
-    q.low = lds_q + (threadIdx.x >> 6) * 2 * kQCap;
-    q.med = q.low + kQCap;
-    q.nlow = q.nmed = 0;
+    q.low = lds_low + (threadIdx.x >> 6) * kQCap;
+    q.seg = lds_seg + (threadIdx.x >> 6) * kQCap;
+    q.nlow = q.nseg = 0;
     unsigned *dcnt = ct->fr_cnt[dst];
-    int *dlow = g.fr_low[dst], *dmed = g.fr_med[dst];
-    int2 *dhigh = g.fr_high[dst];
+    int *dlow = g.fr_low[dst];
+    int2 *dseg = g.fr_seg[dst];
     const i64 S = g.scale;
     const int sh = ct->eps_shift;
     const unsigned stamp = ct->gu_stamp_base + (unsigned)k + 1u;
@@ -426,48 +518,53 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
     const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
+    i64 wmax = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyGuIters]++;
-    const int2 *highl = g.fr_high[src];
-    for (unsigned i = wave; i < nhigh; i += nwaves) {
-        const int2 it = highl[i];
+    const int2 *segl = g.fr_seg[src];
+    for (unsigned i = wave; i < nseg; i += nwaves) {
+        const int2 it = segl[i];
         const int v = it.x;
         const unsigned r0 = g.row[v] + (unsigned)it.y * kWSeg;
         const unsigned r1 = min(g.row[v + 1], r0 + kWSeg);
         const i64 dv = g.dist[v], pv = g.price[v];
-        for (unsigned h = 0; h < kWSeg; h += 256) {
-            const unsigned a0 = r0 + h + lane * 4;
-            int rc4[4];
-            if (a0 + 3 < r1) {
-                int4u x = *reinterpret_cast<const int4u *>(g.rcap + a0);
-                rc4[0] = x.x; rc4[1] = x.y; rc4[2] = x.z; rc4[3] = x.w;
-                t.c[kTallyGuScans] += 4;
-            } else {
+        for (unsigned h = r0; h < r1; h += 512) {
+            const unsigned a0 = h + lane * 8;
+            int rc8[8];
+            load8(g.rcap, a0, r1, rc8);
+            if (a0 < r1) t.c[kTallyGuScans] += min(8u, r1 - a0);
+            bool anyc = false;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const bool ok = a0 + j < r1; rc4[j] = ok ? g.rcap[a0 + j] : 0; if (ok) t.c[kTallyGuScans]++; }
+            for (int j = 0; j < 8; ++j) anyc |= rc8[j] > 0;
+            if (!__ballot(anyc)) continue;
+            int hd[8], cs[8];
+            if (anyc) { load8(g.head, a0, r1, hd); load8(g.cost, a0, r1, cs); }
+            // stage 1: tentative distances; consecutive arcs to the same vertex are merged
+            i64 nd[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                nd[j] = kDistInf;
+                if (anyc && rc8[j] > 0) {
+                    const int u = hd[j];
+                    const i64 rc = -(i64)cs[j] * S + g.price[u] - pv;
+                    i64 l = (rc >> sh) + 1;
+                    if (l < 0) l = 0;
+                    if (dv + l < ld_dist(g, u)) nd[j] = dv + l;
+                }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int u = 0;
+            for (int j = 1; j < 8; ++j) {
+                if (nd[j] < kDistInf && nd[j - 1] < kDistInf && hd[j] == hd[j - 1]) {
+                    nd[j] = nd[j] < nd[j - 1] ? nd[j] : nd[j - 1];
+                    nd[j - 1] = kDistInf;
+                }
+            }
+            // stage 2: commit
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
                 bool enq = false;
-                if (rc4[j] > 0) enq = gu_relax(g, a0 + j, dv, pv, S, sh, stamp, u, t);
-                if (__ballot(enq)) waveq_push(g, q, dcnt, dlow, dmed, dhigh, enq, u);
+                if (nd[j] < kDistInf) enq = gu_commit(g, s_hmin, hd[j], nd[j], stamp, wmax, t);
+                if (__ballot(enq)) waveq_push(g, q, dcnt, dlow, dseg, enq, hd[j]);
             }
-            if (r0 + h + 256 >= r1) break;
-        }
-    }
-    const int *medl = g.fr_med[src];
-    for (unsigned i = wave; i < nmed; i += nwaves) {
-        const int v = medl[i];
-        const unsigned r0 = g.row[v], r1 = g.row[v + 1];
-        const i64 dv = g.dist[v], pv = g.price[v];
-        for (unsigned a = r0 + lane; a - lane < r1; a += 64) {
-            int u = 0;
-            bool enq = false;
-            if (a < r1) {
-                t.c[kTallyGuScans]++;
-                if (g.rcap[a] > 0) enq = gu_relax(g, a, dv, pv, S, sh, stamp, u, t);
-            }
-            if (__ballot(enq)) waveq_push(g, q, dcnt, dlow, dmed, dhigh, enq, u);
         }
     }
     const int *lowl = g.fr_low[src];
@@ -477,27 +574,48 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
         const int v = have ? lowl[i] : 0;
         const unsigned r0 = have ? g.row[v] : 0, r1 = have ? g.row[v + 1] : 0;
         const i64 dv = have ? g.dist[v] : 0, pv = have ? g.price[v] : 0;
+#pragma unroll
         for (unsigned j = 0; j < kLowMax; ++j) {
             const unsigned a = r0 + j;
             int u = 0;
             bool enq = false;
             if (a < r1) {
                 t.c[kTallyGuScans]++;
-                if (g.rcap[a] > 0) enq = gu_relax(g, a, dv, pv, S, sh, stamp, u, t);
+                if (g.rcap[a] > 0) {
+                    u = g.head[a];
+                    const i64 rc = -(i64)g.cost[a] * S + g.price[u] - pv;
+                    i64 l = (rc >> sh) + 1;
+                    if (l < 0) l = 0;
+                    if (dv + l < ld_dist(g, u)) enq = gu_commit(g, s_hmin, u, dv + l, stamp, wmax, t);
+                }
             }
-            if (__ballot(enq)) waveq_push(g, q, dcnt, dlow, dmed, dhigh, enq, u);
+            if (__ballot(enq)) waveq_push(g, q, dcnt, dlow, dseg, enq, u);
         }
     }
+    __syncthreads();  // hub minima of the whole workgroup are in LDS
+    for (int base = 0; base < g.nhubs; base += kBlock) {
+        const int i = base + (int)threadIdx.x;
+        bool enq = false;
+        int u = 0;
+        if (i < g.nhubs && s_hmin[i] < kDistInf) {
+            u = g.hub_vertex[i];
+            if (s_hmin[i] < ld_dist(g, u)) enq = gu_commit_global(g, u, s_hmin[i], stamp, wmax, t);
+        }
+        if (__ballot(enq)) waveq_push(g, q, dcnt, dlow, dseg, enq, u);
+    }
     waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
-    waveq_flush_one(q.med, q.nmed, &dcnt[kClsMed], dmed);
-    tally_flush(g, t);
+    waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);
+    wmax = wave_max(wmax);
+    if (lane == 0 && wmax > ct->dmax) amax64(&ct->dmax, wmax);
+    tally_flush<kTallyGuScans, kTallyGuRelax, kTallyGuIters>(g, t);
 }
 
 // dist = 0 at deficits (they seed frontier 0), "infinite" elsewhere.
 __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_init_on) return;
-    const int nround = (g.n + 63) & ~63;
+    __shared__ unsigned s_app[2][kBlock / 64 + 1];
+    const int nround = (g.n + kBlock - 1) / kBlock * kBlock;
     for (int v = blockIdx.x * kBlock + threadIdx.x; v < nround; v += gridDim.x * kBlock) {
         bool def = false;
         int cls = 0;
@@ -506,22 +624,13 @@ __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) {
             g.dist[v] = def ? 0 : kDistInf;
             cls = g.cls[v];
         }
-        wave_append(g, ct->fr_cnt[0], g.fr_low[0], g.fr_med[0], g.fr_high[0], def, v, cls);
+        block_append(g, ct->fr_cnt[0], g.fr_low[0], g.fr_seg[0], def, v, cls, s_app);
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_gu_dmax(DevGraph g) {
-    Ctrl *ct = g.ctrl;
-    if (!ct->gu_apply_on) return;
-    i64 mx = 0;
-    for (int v = blockIdx.x * kBlock + threadIdx.x; v < g.n; v += gridDim.x * kBlock) {
-        const i64 d = g.dist[v];
-        if (d < kDistInf && d > mx) mx = d;
-    }
-    mx = wave_max(mx);
-    if (lane_id() == 0 && mx > 0) amax64(&ct->dmax, mx);
-}
-
+// price[v] -= eps * dist[v]; vertices that reach no deficit move by one more than the
+// largest distance handed out (any value >= the largest final distance keeps every
+// residual arc eps-optimal).
 __global__ __launch_bounds__(kBlock) void k_gu_apply(DevGraph g) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_apply_on) return;
@@ -561,7 +670,7 @@ __global__ void k_mid(DevGraph g, int n_iters) {
     if (ct->done || ct->error) return;
     if (ct->gu_on) {
         const unsigned *c = ct->fr_cnt[n_iters % 3];
-        if (c[kClsLow] + c[kClsMed] + c[kClsHigh] == 0) {
+        if (c[kClsLow] + c[kClsSeg] == 0) {
             ct->gu_apply_on = 1; ct->gu_active = 0; ct->need_gu = 0; ct->rounds_on = 1;
         }
     } else {
@@ -573,7 +682,7 @@ __global__ void k_end(DevGraph g, int n_rounds) {
     Ctrl *ct = g.ctrl;
     if (ct->done || ct->error || !ct->rounds_on) return;
     const unsigned *c = ct->list_cnt[n_rounds & 1];
-    if (c[kClsLow] + c[kClsMed] + c[kClsHigh] == 0) {
+    if (c[kClsLow] + c[kClsSeg] == 0) {
         if (ct->eps_shift == 0) { ct->done = 1; return; }
         ct->eps_shift = ct->eps_shift > ct->alpha_log2 ? ct->eps_shift - ct->alpha_log2 : 0;
         ct->eps = (i64)1 << ct->eps_shift;
