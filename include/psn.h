@@ -48,10 +48,19 @@ typedef struct psn_config {
     int32_t flags;           /* PSN_CFG_* */
 } psn_config;
 #define PSN_CFG_EAGER 1      /* plain launches instead of hipGraph replay (debugging) */
+#define PSN_CFG_KTIME 2      /* with PSN_CFG_EAGER: HIP-event time every sweep launch (psn_kernel_times) */
+
+/* kernel classes reported by psn_kernel_times */
+#define PSN_KT_PUSH 0        /* push sweep over the active lists */
+#define PSN_KT_GU_EXPAND 1   /* global price update: frontier expansion */
+#define PSN_KT_RELABEL 2     /* relabel + active-list compaction */
+#define PSN_KT_SATURATE 3    /* per-phase saturation sweep */
+#define PSN_KT_OTHER 4
+#define PSN_KT_CLASSES 5
 
 /* Result of one solve.  Counters are what the kernels actually did; bytes follow
  * from them (20 B per arc scan, 36 B per push, 32 B per vertex visit, 8 B per
- * relabel, see DESIGN.md). */
+ * relabel). */
 typedef struct psn_result {
     int64_t total_cost;      /* sum over arcs of flow * cost */
     int32_t status;          /* PSN_OK or PSN_E* */
@@ -130,6 +139,20 @@ int psn_get_residual(psn_ctx *ctx, int32_t *cap /* m2 */);
 int psn_get_prices(psn_ctx *ctx, int64_t *price /* n */);
 int psn_get_costs(psn_ctx *ctx, int32_t *cost /* m2 */, int32_t *cap_orig /* m2 */);
 int psn_get_placements(psn_ctx *ctx, const psn_layout *layout, int32_t *task_to_machine /* P */);
+
+/* Same as psn_get_placements but into caller-owned device memory (int32[P]) on this
+ * context's GPU, e.g. the send buffer of an all-gather; returns after the copy is done. */
+int psn_get_placements_device(psn_ctx *ctx, const psn_layout *layout, void *dst_device);
+
+/* Per-kernel-class device time (ms) and launch counts of the last psn_solve, measured
+ * with HIP events on the solver's stream; all zero unless the context was created with
+ * PSN_CFG_EAGER | PSN_CFG_KTIME.  Arrays of PSN_KT_CLASSES entries. */
+int psn_kernel_times(psn_ctx *ctx, double *ms, uint64_t *calls);
+
+/* Development aid: with PSN_TRACE=1 in the environment when a network is uploaded, one
+ * record (kind: 1 push / 2 global-update expand, k, lane-list size, item-list size) per
+ * sweep launch that had work during the last solve. */
+int psn_debug_trace(psn_ctx *ctx, int32_t *out4, int64_t max_records, int64_t *count);
 
 /* Device pointer to the last placements (int32[P]) for collectives that gather
  * placements across GPUs without a host round trip; valid until the next call. */

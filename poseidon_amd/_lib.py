@@ -17,12 +17,14 @@ PSN_EINVAL, PSN_ENOMEM, PSN_EDEVICE, PSN_EINFEASIBLE = -1, -2, -3, -4
 PSN_EOVERFLOW, PSN_ESTATE, PSN_ELIMIT = -5, -6, -7
 PSN_WARM_START = 1
 PSN_CFG_EAGER = 1
+PSN_CFG_KTIME = 2
+KT_NAMES = ["push", "gu_expand", "relabel_compact", "saturate", "other"]
 
 EXPORTS = [
     "psn_version", "psn_strerror", "psn_last_error", "psn_create", "psn_destroy",
     "psn_upload_csr", "psn_eval_costs", "psn_update_caps", "psn_update_supplies", "psn_solve",
     "psn_get_flow", "psn_get_residual", "psn_get_prices", "psn_get_costs", "psn_get_placements",
-    "psn_placements_device_ptr",
+    "psn_placements_device_ptr", "psn_get_placements_device", "psn_kernel_times", "psn_debug_trace",
     "psn_synth_cluster", "psn_network_size", "psn_build_network", "psn_fnv1a64",
 ]
 
@@ -82,6 +84,8 @@ def load_library():
     lib.psn_get_prices.argtypes = [vp, vp]
     lib.psn_get_costs.argtypes = [vp, vp, vp]
     lib.psn_get_placements.argtypes = [vp, C.POINTER(Layout), vp]
+    lib.psn_get_placements_device.argtypes = [vp, C.POINTER(Layout), vp]
+    lib.psn_kernel_times.argtypes = [vp, vp, vp]
     lib.psn_placements_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     lib.psn_synth_cluster.argtypes = [i32, u64, C.POINTER(Layout), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.psn_network_size.argtypes = [C.POINTER(Layout), C.POINTER(i32), C.POINTER(i64)]

@@ -45,6 +45,12 @@ struct psn_ctx {
     int rounds = 8;
     int launches_per_replay = 0;
     Ctrl *h_ctrl = nullptr;  // pinned
+    // per-kernel-class timing (PSN_CFG_KTIME, eager launches only): event pairs per launch
+    std::vector<hipEvent_t> kt_ev;
+    std::vector<int> kt_cls;
+    size_t kt_used = 0;
+    double kt_ms[PSN_KT_CLASSES] = {0};
+    uint64_t kt_calls[PSN_KT_CLASSES] = {0};
 };
 
 namespace {
@@ -86,21 +92,35 @@ int enqueue_replay(psn_ctx *c, hipStream_t s) {
     const DevGraph &g = c->g;
     int launches = 0;
     const int gv = std::max(1, std::min(kGrid, (g.n + kBlock - 1) / kBlock));  // vertex sweeps
-#define L(kern, grid, ...)                                                \
+    const bool timed = (c->cfg.flags & PSN_CFG_KTIME) && !c->gexec;
+    auto mark = [&](int cls, bool begin) {
+        if (!timed) return;
+        if (c->kt_used == c->kt_ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            c->kt_ev.push_back(e);
+            c->kt_cls.push_back(0);
+        }
+        c->kt_cls[c->kt_used] = begin ? cls : -1;
+        (void)hipEventRecord(c->kt_ev[c->kt_used++], s);
+    };
+#define L(cls, kern, grid, ...)                                           \
     do {                                                                  \
+        mark(cls, true);                                                  \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, __VA_ARGS__); \
+        mark(cls, false);                                                 \
         ++launches;                                                       \
     } while (0)
     hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, g); ++launches;
-    L(k_saturate, kGrid, g);
-    L(k_gu_init, gv, g);
-    for (int k = 0; k < kGuIters; ++k) L(k_gu_expand, kGrid, g, k);
+    L(PSN_KT_SATURATE, k_saturate, kGrid, g);
+    L(PSN_KT_OTHER, k_gu_init, gv, g);
+    for (int k = 0; k < kGuIters; ++k) L(PSN_KT_GU_EXPAND, k_gu_expand, kGrid, g, k);
     hipLaunchKernelGGL(k_mid, dim3(1), dim3(1), 0, s, g, kGuIters); ++launches;
-    L(k_gu_apply, gv, g);
-    L(k_relabel_compact, gv, g, 0, 0);
+    L(PSN_KT_OTHER, k_gu_apply, gv, g);
+    L(PSN_KT_RELABEL, k_relabel_compact, gv, g, 0, 0);
     for (int k = 0; k < c->rounds; ++k) {
-        L(k_push, kGrid, g, k);
-        L(k_relabel_compact, gv, g, k, 1);
+        L(PSN_KT_PUSH, k_push, kGrid, g, k);
+        L(PSN_KT_RELABEL, k_relabel_compact, gv, g, k, 1);
     }
     hipLaunchKernelGGL(k_end, dim3(1), dim3(1), 0, s, g, c->rounds); ++launches;
 #undef L
@@ -196,6 +216,7 @@ void psn_destroy(psn_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->kt_ev) (void)hipEventDestroy(e);
     free_graph_buffers(c);
     if (c->h_ctrl) (void)hipHostFree(c->h_ctrl);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -282,6 +303,7 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     for (int i = 0; i < 3; ++i) { A(g.fr_low[i], n) A(g.fr_seg[i], (size_t)n + high_items) }
     c->tally_slots = kGrid * (kBlock / 64);
     A(g.tally, (size_t)c->tally_slots * kTallyN) A(c->d_tally_out, kTallyN) A(g.ctrl, 1)
+    if (std::getenv("PSN_TRACE")) { A(g.dbg, kDbgCap) A(g.dbg_cnt, 1) }
 #undef A
     g.row = d_row; g.head = d_head; g.cost = c->d_cost; g.rev = d_rev; g.tail = d_tail; g.ocap = c->d_ocap; g.cls = d_cls;
     g.hub_of = d_hub_of; g.hub_vertex = d_hub_vertex; g.nhubs = nhubs;
@@ -405,6 +427,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
     const bool warm = (flags & PSN_WARM_START) && c->solved;
     HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < PSN_KT_CLASSES; ++i) { c->kt_ms[i] = 0; c->kt_calls[i] = 0; }
     hipStream_t s = c->stream;
     const DevGraph &g = c->g;
     // supplies must still balance (psn_update_supplies may have changed them)
@@ -414,6 +437,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     if (warm) hipLaunchKernelGGL(k_excess_from_flow, dim3(kGrid), dim3(kBlock), 0, s, g);
     HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 8 * sizeof(i64), s));
     HIPCHK(c, hipMemsetAsync(g.tally, 0, (size_t)c->tally_slots * kTallyN * sizeof(unsigned long long), s));
+    if (g.dbg_cnt) HIPCHK(c, hipMemsetAsync(g.dbg_cnt, 0, sizeof(unsigned), s));
     hipLaunchKernelGGL(k_max_abs_cost, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 1);
     if (warm) hipLaunchKernelGGL(k_max_violation, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 2);
     i64 h_scalar[3] = {0, 0, 0};
@@ -449,6 +473,15 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
         ++replays;
         HIPCHK(c, hipMemcpyAsync(c->h_ctrl, g.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        for (size_t i = 0; i + 1 < c->kt_used; i += 2) {  // event pairs of this replay
+            float ems = 0.f;
+            const int cls = c->kt_cls[i];
+            if (cls >= 0 && hipEventElapsedTime(&ems, c->kt_ev[i], c->kt_ev[i + 1]) == hipSuccess) {
+                c->kt_ms[cls] += ems;
+                c->kt_calls[cls] += 1;
+            }
+        }
+        c->kt_used = 0;
         if (c->h_ctrl->error) { status = c->h_ctrl->error == PSN_EINFEASIBLE_DEV ? PSN_EINFEASIBLE : PSN_EDEVICE; break; }
         if (c->h_ctrl->done) break;
         if (replays >= max_replays) { status = PSN_ELIMIT; break; }
@@ -548,6 +581,36 @@ int psn_get_placements(psn_ctx *c, const psn_layout *lay, int32_t *task_to_machi
     int rc = run_placements(c, lay);
     if (rc != PSN_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(task_to_machine, c->d_place, (size_t)lay->n_tasks * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSN_OK;
+}
+
+// Development aid (PSN_TRACE=1 in the environment at upload time): one record per sweep
+// launch that had work: kind (1 push, 2 global-update expand), k, lane-list size, item-list size.
+int psn_debug_trace(psn_ctx *c, int32_t *out4, int64_t max_records, int64_t *count) {
+    if (!c || !out4 || !count) return fail(c, PSN_EINVAL, "null argument");
+    *count = 0;
+    if (!c->uploaded || !c->g.dbg) return PSN_OK;
+    unsigned n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->g.dbg_cnt, sizeof(unsigned), hipMemcpyDeviceToHost));
+    n = std::min<unsigned>(n, kDbgCap);
+    n = (unsigned)std::min<int64_t>(n, max_records);
+    HIPCHK(c, hipMemcpy(out4, c->g.dbg, (size_t)n * sizeof(int4), hipMemcpyDeviceToHost));
+    *count = n;
+    return PSN_OK;
+}
+
+int psn_kernel_times(psn_ctx *c, double *ms, uint64_t *calls) {
+    if (!c || !ms || !calls) return fail(c, PSN_EINVAL, "null argument");
+    for (int i = 0; i < PSN_KT_CLASSES; ++i) { ms[i] = c->kt_ms[i]; calls[i] = c->kt_calls[i]; }
+    return PSN_OK;
+}
+
+int psn_get_placements_device(psn_ctx *c, const psn_layout *lay, void *dst_device) {
+    if (!c || !dst_device) return fail(c, PSN_EINVAL, "null argument");
+    int rc = run_placements(c, lay);
+    if (rc != PSN_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(dst_device, c->d_place, (size_t)lay->n_tasks * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PSN_OK;
 }

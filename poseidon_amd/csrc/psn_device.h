@@ -15,7 +15,7 @@ constexpr int kGrid = 1024;      // workgroups per sweep launch: 16 waves per CU
 constexpr unsigned kLowMax = 4;  // degree <= kLowMax: one lane per vertex
 constexpr unsigned kWSeg = 1024; // arcs per wave work item; larger vertices are split into several items
 constexpr unsigned kMedMax = kWSeg;  // degree <= kMedMax: the whole vertex is one wave item
-constexpr unsigned kQCap = 256;  // entries per per-wave LDS frontier staging queue
+constexpr unsigned kQCap = 512;  // entries per per-wave LDS frontier staging queue
 constexpr int kClsLow = 0, kClsMed = 1, kClsHigh = 2;  // vertex classes by degree
 constexpr int kClsSeg = 1;       // counter slot of the (vertex, segment) item lists (slot 0: lane list)
 constexpr int kMaxHubs = 128;    // highest-degree vertices whose atomics are pre-combined in LDS per workgroup
@@ -66,7 +66,10 @@ struct DevGraph {
     int2 *fr_seg[3];
     unsigned long long *tally;
     Ctrl *ctrl;
+    int4 *dbg;          // optional launch trace (kind, k, lane-list size, item-list size); null when off
+    unsigned *dbg_cnt;
 };
+constexpr unsigned kDbgCap = 1u << 16;
 
 __global__ void k_push(DevGraph g, int k);
 __global__ void k_relabel_compact(DevGraph g, int k, int do_relabel);

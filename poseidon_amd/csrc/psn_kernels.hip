@@ -276,12 +276,27 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
             }
             i64 mine = granted - (incl - want);  // what this lane may push
             if (mine > 0) {
+                // amounts first, then every load of the batch before any dependent store
+                i64 d[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    if (key[j] > pu && mine > 0) {
-                        const i64 d = mine < cp[j] ? mine : cp[j];
-                        do_push(g, hb, a0 + j, hd[j], cp[j], d, pu, (i64)cs[j] * S);
-                        cp[j] -= (int)d; mine -= d;
+                    d[j] = 0;
+                    if (key[j] > pu && mine > 0) { d[j] = mine < cp[j] ? mine : cp[j]; mine -= d[j]; }
+                }
+                int rv[8], cr[8], hub[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { rv[j] = d[j] > 0 ? g.rev[a0 + j] : 0; hub[j] = d[j] > 0 ? g.hub_of[hd[j]] : -1; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cr[j] = d[j] > 0 ? g.cap[rv[j]] : 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (d[j] > 0) {
+                        const int na = cp[j] - (int)d[j], nr = cr[j] + (int)d[j];
+                        g.cap[a0 + j] = na; g.cap[rv[j]] = nr; g.rcap[a0 + j] = nr; g.rcap[rv[j]] = na;
+                        const i64 kr = pu + (i64)cs[j] * S;  // key of the new residual arc (v,u)
+                        if (hub[j] >= 0) { lds_add(&hb.add[hub[j]], d[j]); lds_max(&hb.ext[hub[j]], kr); }
+                        else { aadd64(&g.excess[hd[j]], d[j]); amax64(&g.cand[hd[j]], kr); }
+                        cp[j] = na;
                         t.c[kTallyPushes]++;
                     }
                 }
@@ -311,6 +326,10 @@ __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
     const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg];
     if (blockIdx.x == 0 && threadIdx.x < 4) ct->list_cnt[(k + 1) & 1][threadIdx.x] = 0;
     if (nlow + nseg == 0) return;
+    if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned i = aadd32(g.dbg_cnt, 1u);
+        if (i < kDbgCap) g.dbg[i] = make_int4(1, k, (int)nlow, (int)nseg);
+    }
     __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
     const HubAcc hb{s_add, s_max};
     hub_init(hb, kNegInf);
@@ -449,26 +468,11 @@ __device__ __forceinline__ void waveq_flush_one(T *q, unsigned &n, unsigned *cnt
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     n = 0;
 }
-__device__ __forceinline__ void waveq_push(const DevGraph &g, WaveQ &q, unsigned *cnt, int *lowl, int2 *segl, bool take, int v) {
-    const int cls = take ? g.cls[v] : 0;
-    const unsigned long long lt = lanemask_lt();
-    unsigned long long m = __ballot(take && cls == kClsLow);
-    if (m) {
-        if (take && cls == kClsLow) q.low[q.nlow + __popcll(m & lt)] = v;
-        q.nlow += (unsigned)__popcll(m);
-        if (q.nlow > kQCap - 64) waveq_flush_one(q.low, q.nlow, &cnt[kClsLow], lowl);
-    }
-    m = __ballot(take && cls == kClsMed);
-    if (m) {
-        if (take && cls == kClsMed) q.seg[q.nseg + __popcll(m & lt)] = make_int2(v, 0);
-        q.nseg += (unsigned)__popcll(m);
-        if (q.nseg > kQCap - 64) waveq_flush_one(q.seg, q.nseg, &cnt[kClsSeg], segl);
-    }
-    if (take && cls == kClsHigh) {
-        const unsigned nseg = nseg_of(g, v);
-        const unsigned base = aadd32(&cnt[kClsSeg], nseg);
-        for (unsigned s = 0; s < nseg; ++s) segl[base + s] = make_int2(v, (int)s);
-    }
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { unsigned y = __shfl_up(x, d); if (l >= d) x += y; }
+    return x;
 }
 
 // Distances are lowered by atomics during the sweep, so pre-checks read them past the
@@ -476,19 +480,85 @@ __device__ __forceinline__ void waveq_push(const DevGraph &g, WaveQ &q, unsigned
 __device__ __forceinline__ i64 ld_dist(const DevGraph &g, int u) {
     return __hip_atomic_load(&g.dist[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Try dist[u] = nd; true if this lane is the one that must queue u for the next iteration.
-__device__ __forceinline__ bool gu_commit_global(const DevGraph &g, int u, i64 nd, unsigned stamp, i64 &wmax, Tally &t) {
-    const i64 old = amin64(&g.dist[u], nd);
-    if (nd >= old) return false;
-    t.c[kTallyGuRelax]++;
-    if (nd > wmax) wmax = nd;
-    return axchg32(&g.fstamp[u], stamp) != stamp;  // first improver in this iteration queues u
-}
+
+// Commit up to NJ tentative distances per lane (nd[j] == kDistInf: none) and queue the
+// vertices this wave is the first to improve in this iteration.  Every memory round trip
+// (hub lookup, atomic min, stamp exchange, class lookup) is issued for all NJ candidates
+// before any result is used, so a lane pays each latency once per step, not once per arc.
 // Hubs are only lowered in LDS here; the workgroup commits them once at the end.
-__device__ __forceinline__ bool gu_commit(const DevGraph &g, i64 *hub_min, int u, i64 nd, unsigned stamp, i64 &wmax, Tally &t) {
-    const int h = g.hub_of[u];
-    if (h >= 0) { lds_min(&hub_min[h], nd); return false; }
-    return gu_commit_global(g, u, nd, stamp, wmax, t);
+template <int NJ>
+__device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, unsigned *dcnt, int *dlow, int2 *dseg, i64 *hub_min,
+                                                const int (&hd)[NJ], i64 (&nd)[NJ], unsigned stamp, i64 &wmax, Tally &t) {
+    bool anyc = false;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) anyc |= nd[j] < kDistInf;
+    if (!__ballot(anyc)) return;
+    int hub[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) hub[j] = nd[j] < kDistInf ? g.hub_of[hd[j]] : -1;
+    i64 old[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        old[j] = kNegInf;
+        if (nd[j] < kDistInf) {
+            if (hub[j] >= 0) lds_min(&hub_min[hub[j]], nd[j]);
+            else old[j] = amin64(&g.dist[hd[j]], nd[j]);
+        }
+    }
+    unsigned st[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        st[j] = stamp;
+        if (nd[j] < old[j]) {  // improved (old stays -inf for "no candidate" and for hubs)
+            t.c[kTallyGuRelax]++;
+            if (nd[j] > wmax) wmax = nd[j];
+            st[j] = axchg32(&g.fstamp[hd[j]], stamp);
+        }
+    }
+    int cls[NJ];
+    unsigned nl = 0, ns = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) cls[j] = st[j] != stamp ? (int)g.cls[hd[j]] : -1;  // first improver queues it
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { nl += cls[j] == kClsLow; ns += cls[j] == kClsMed; }
+    if (!__ballot((nl | ns) != 0)) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (cls[j] == kClsHigh) {
+            const unsigned nseg = nseg_of(g, hd[j]);
+            const unsigned base = aadd32(&dcnt[kClsSeg], nseg);
+            for (unsigned s = 0; s < nseg; ++s) dseg[base + s] = make_int2(hd[j], (int)s);
+        }
+        return;
+    }
+    // lane-list entries
+    {
+        const unsigned incl = wave_incl_scan_u32(nl);
+        const unsigned tot = __shfl(incl, 63);
+        if (tot) {
+            if (q.nlow + tot > kQCap) waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
+            unsigned pos = q.nlow + incl - nl;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsLow) q.low[pos++] = hd[j];
+            q.nlow += tot;
+        }
+    }
+    {
+        const unsigned incl = wave_incl_scan_u32(ns);
+        const unsigned tot = __shfl(incl, 63);
+        if (tot) {
+            if (q.nseg + tot > kQCap) waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);
+            unsigned pos = q.nseg + incl - ns;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsMed) q.seg[pos++] = make_int2(hd[j], 0);
+            q.nseg += tot;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) if (cls[j] == kClsHigh) {
+        const unsigned nseg = nseg_of(g, hd[j]);
+        const unsigned base = aadd32(&dcnt[kClsSeg], nseg);
+        for (unsigned s = 0; s < nseg; ++s) dseg[base + s] = make_int2(hd[j], (int)s);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
@@ -499,6 +569,10 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
     const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg];
     if (blockIdx.x == 0 && threadIdx.x < 4) ct->fr_cnt[clr][threadIdx.x] = 0;
     if (nlow + nseg == 0) return;
+    if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned i = aadd32(g.dbg_cnt, 1u);
+        if (i < kDbgCap) g.dbg[i] = make_int4(2, k, (int)nlow, (int)nseg);
+    }
     __shared__ int lds_low[(kBlock / 64) * kQCap];
     __shared__ int2 lds_seg[(kBlock / 64) * kQCap];
     __shared__ i64 s_hmin[kMaxHubs];
@@ -538,17 +612,26 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
             if (!__ballot(anyc)) continue;
             int hd[8], cs[8];
             if (anyc) { load8(g.head, a0, r1, hd); load8(g.cost, a0, r1, cs); }
-            // stage 1: tentative distances; consecutive arcs to the same vertex are merged
-            i64 nd[8];
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { hd[j] = 0; cs[j] = 0; }
+            }
+            // tentative distances; consecutive arcs to the same vertex are merged
+            i64 pu[8], du[8], nd[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = rc8[j] > 0;
+                pu[j] = ok ? g.price[hd[j]] : 0;
+                du[j] = ok ? ld_dist(g, hd[j]) : 0;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 nd[j] = kDistInf;
-                if (anyc && rc8[j] > 0) {
-                    const int u = hd[j];
-                    const i64 rc = -(i64)cs[j] * S + g.price[u] - pv;
+                if (rc8[j] > 0) {
+                    const i64 rc = -(i64)cs[j] * S + pu[j] - pv;
                     i64 l = (rc >> sh) + 1;
                     if (l < 0) l = 0;
-                    if (dv + l < ld_dist(g, u)) nd[j] = dv + l;
+                    if (dv + l < du[j]) nd[j] = dv + l;
                 }
             }
 #pragma unroll
@@ -558,13 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
                     nd[j - 1] = kDistInf;
                 }
             }
-            // stage 2: commit
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bool enq = false;
-                if (nd[j] < kDistInf) enq = gu_commit(g, s_hmin, hd[j], nd[j], stamp, wmax, t);
-                if (__ballot(enq)) waveq_push(g, q, dcnt, dlow, dseg, enq, hd[j]);
-            }
+            gu_commit_batch<8>(g, q, dcnt, dlow, dseg, s_hmin, hd, nd, stamp, wmax, t);
         }
     }
     const int *lowl = g.fr_low[src];
@@ -574,34 +651,53 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
         const int v = have ? lowl[i] : 0;
         const unsigned r0 = have ? g.row[v] : 0, r1 = have ? g.row[v + 1] : 0;
         const i64 dv = have ? g.dist[v] : 0, pv = have ? g.price[v] : 0;
+        int rc4[kLowMax], hd[kLowMax], cs[kLowMax];
+        i64 pu[kLowMax], du[kLowMax], nd[kLowMax];
+#pragma unroll
+        for (unsigned j = 0; j < kLowMax; ++j) rc4[j] = r0 + j < r1 ? g.rcap[r0 + j] : 0;
+        t.c[kTallyGuScans] += r1 - r0;
+#pragma unroll
+        for (unsigned j = 0; j < kLowMax; ++j) { hd[j] = rc4[j] > 0 ? g.head[r0 + j] : 0; cs[j] = rc4[j] > 0 ? g.cost[r0 + j] : 0; }
+#pragma unroll
+        for (unsigned j = 0; j < kLowMax; ++j) { pu[j] = rc4[j] > 0 ? g.price[hd[j]] : 0; du[j] = rc4[j] > 0 ? ld_dist(g, hd[j]) : 0; }
 #pragma unroll
         for (unsigned j = 0; j < kLowMax; ++j) {
-            const unsigned a = r0 + j;
-            int u = 0;
-            bool enq = false;
-            if (a < r1) {
-                t.c[kTallyGuScans]++;
-                if (g.rcap[a] > 0) {
-                    u = g.head[a];
-                    const i64 rc = -(i64)g.cost[a] * S + g.price[u] - pv;
-                    i64 l = (rc >> sh) + 1;
-                    if (l < 0) l = 0;
-                    if (dv + l < ld_dist(g, u)) enq = gu_commit(g, s_hmin, u, dv + l, stamp, wmax, t);
-                }
+            nd[j] = kDistInf;
+            if (rc4[j] > 0) {
+                const i64 rc = -(i64)cs[j] * S + pu[j] - pv;
+                i64 l = (rc >> sh) + 1;
+                if (l < 0) l = 0;
+                if (dv + l < du[j]) nd[j] = dv + l;
             }
-            if (__ballot(enq)) waveq_push(g, q, dcnt, dlow, dseg, enq, u);
         }
+        gu_commit_batch<(int)kLowMax>(g, q, dcnt, dlow, dseg, s_hmin, hd, nd, stamp, wmax, t);
     }
     __syncthreads();  // hub minima of the whole workgroup are in LDS
     for (int base = 0; base < g.nhubs; base += kBlock) {
         const int i = base + (int)threadIdx.x;
-        bool enq = false;
-        int u = 0;
+        int hd[1] = {0};
+        i64 nd[1] = {kDistInf};
         if (i < g.nhubs && s_hmin[i] < kDistInf) {
-            u = g.hub_vertex[i];
-            if (s_hmin[i] < ld_dist(g, u)) enq = gu_commit_global(g, u, s_hmin[i], stamp, wmax, t);
+            hd[0] = g.hub_vertex[i];
+            if (s_hmin[i] < ld_dist(g, hd[0])) nd[0] = s_hmin[i];
         }
-        if (__ballot(enq)) waveq_push(g, q, dcnt, dlow, dseg, enq, u);
+        bool anyc = nd[0] < kDistInf;
+        if (__ballot(anyc)) {
+            bool enq = false;
+            if (anyc) {
+                const i64 old = amin64(&g.dist[hd[0]], nd[0]);
+                if (nd[0] < old) {
+                    t.c[kTallyGuRelax]++;
+                    if (nd[0] > wmax) wmax = nd[0];
+                    enq = axchg32(&g.fstamp[hd[0]], stamp) != stamp;
+                }
+            }
+            if (enq) {  // hubs are always multi-item vertices
+                const unsigned ns = nseg_of(g, hd[0]);
+                const unsigned b = aadd32(&dcnt[kClsSeg], ns);
+                for (unsigned s2 = 0; s2 < ns; ++s2) dseg[b + s2] = make_int2(hd[0], (int)s2);
+            }
+        }
     }
     waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
     waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);

@@ -38,10 +38,11 @@ class SolveResult:
 
 class Solver:
     def __init__(self, device: int = 0, alpha_log2: int = 0, rounds_per_batch: int = 0,
-                 eager: bool = False):
+                 eager: bool = False, time_kernels: bool = False):
         self._lib = _lib.load_library()
         self._ctx = C.c_void_p(None)
-        cfg = _lib.Config(device, alpha_log2, rounds_per_batch, _lib.PSN_CFG_EAGER if eager else 0)
+        flags = (_lib.PSN_CFG_EAGER if eager or time_kernels else 0) | (_lib.PSN_CFG_KTIME if time_kernels else 0)
+        cfg = _lib.Config(device, alpha_log2, rounds_per_batch, flags)
         rc = self._lib.psn_create(C.byref(cfg), C.byref(self._ctx))
         if rc != _lib.PSN_OK:
             self._ctx = C.c_void_p(None)
@@ -133,6 +134,18 @@ class Solver:
         out = np.empty(layout.n_tasks, np.int32)
         self._chk(self._lib.psn_get_placements(self._ctx, C.byref(layout), _vp(out)))
         return out
+
+    def placements_into(self, device_ptr: int, layout=None):
+        """Placement extraction straight into caller-owned device memory (int32[P])."""
+        layout = layout or self.layout
+        self._chk(self._lib.psn_get_placements_device(self._ctx, C.byref(layout), C.c_void_p(device_ptr)))
+
+    def kernel_times(self):
+        """{class name: (total device ms, launches)} of the last solve (time_kernels=True)."""
+        ms = (C.c_double * len(_lib.KT_NAMES))()
+        calls = (C.c_uint64 * len(_lib.KT_NAMES))()
+        self._chk(self._lib.psn_kernel_times(self._ctx, ms, calls))
+        return {nm: (ms[i], int(calls[i])) for i, nm in enumerate(_lib.KT_NAMES)}
 
     def placements_device_ptr(self):
         p = C.c_void_p(None)

@@ -1,0 +1,73 @@
+"""Generates tests/golden/psn_synth_v1.json.
+
+For every (config, seed) of the synthetic family psn-synth-v1 it records the network
+sizes, the FNV-1a-64 checksum of the residual CSR, the optimal cost found by the two C
+oracles (successive shortest paths where affordable, cost scaling always, both passing
+the optimality certificate) and, for the sizes it can finish, the optimal cost found by
+an independent third-party solver that ships in this container: networkx 3.4.2
+`network_simplex`.  No reference solver exists to generate vectors from (Firmament is
+absent from /root/reference), so these numbers pin the oracle against independent
+mathematics, not against the reference: parity with the reference stays unpinned.
+
+Run from the repo root:  python tests/golden/make_golden.py [--nx-c1]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+from oracle import capi, synth
+
+
+def nx_cost(g):
+    import networkx as nx
+    G = nx.MultiDiGraph()
+    for v in range(g.n):
+        G.add_node(v, demand=int(-g.supply[v]))
+    tail = np.repeat(np.arange(g.n), np.diff(g.row_off))
+    for a in g.fwd_pos:
+        if g.cap[a] > 0:
+            G.add_edge(int(tail[a]), int(g.head[a]), capacity=int(g.cap[a]), weight=int(g.cost[a]))
+    cost, _ = nx.network_simplex(G)
+    return int(cost)
+
+
+def main():
+    nx_c1 = "--nx-c1" in sys.argv
+    out = {"family": "psn-synth-v1", "entries": []}
+    for cfg in (0, 1, 2):
+        for seed in (1, 2, 3):
+            cl = synth.make_cluster(cfg, seed)
+            g = synth.build_graph(cl)
+            e = {"config": cfg, "seed": seed, "n": g.n, "m": g.m, "n_machines": cl.n_machines, "n_pods": cl.n_pods,
+                 "csr_fnv1a64": "%016x" % capi.csr_checksum(g)}
+            t = time.time()
+            rc, tc, cap, price, st = capi.cost_scaling(g)
+            assert rc == 0
+            crc, ctc, _ = capi.check(g, cap, price)
+            assert crc == 0 and ctc == tc
+            e["cost_scaling"] = tc
+            e["cost_scaling_s"] = round(time.time() - t, 2)
+            if cfg <= 1:
+                rc, tcs, caps, _ = capi.ssp(g)
+                assert rc == 0 and capi.check(g, caps)[0] == 0
+                e["ssp"] = tcs
+                assert tcs == tc
+            if cfg == 0 or (cfg == 1 and nx_c1):
+                t = time.time()
+                e["networkx_network_simplex"] = nx_cost(g)
+                e["networkx_s"] = round(time.time() - t, 1)
+                assert e["networkx_network_simplex"] == tc
+            e["optimal_cost"] = tc
+            print(e, flush=True)
+            out["entries"].append(e)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "psn_synth_v1.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
