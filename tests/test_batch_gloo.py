@@ -1,0 +1,93 @@
+"""N > 1 path on CPU: two processes over gloo shard a batch of networks round robin,
+each produces the placements of its share (here from the oracle's flow: the product
+solver needs a GPU) and one all-gather rebuilds the full batch in graph order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_placements(cfg, seed, nm, np_):
+    from oracle import capi, synth
+    cl = synth.make_cluster(cfg, seed, nm, np_)
+    g = synth.build_graph(cl)
+    rc, tc, cap, _, _ = capi.cost_scaling(g)
+    assert rc == 0
+    # task -> machine by walking the flow: class e's routed tasks (arc order) take its units (arc order)
+    N, E, J, P, K = g.n_machines, g.n_ec, g.n_jobs, g.n_pods, cl.k_slots
+    place = np.full(P, -1, np.int32)
+    flow = g.cap - cap
+    for e in range(E):
+        u = 1 + N + e
+        r0, r1 = g.row_off[u], g.row_off[u + 1]
+        t1 = r1 - N * K
+        units = []
+        for a in range(t1, r1):
+            units += [g.head[a] - 1] * max(0, int(flow[a]))
+        tasks = [g.head[a] - (1 + N + E + J) for a in range(r0, t1) if cap[a] > 0]
+        for t, m in zip(tasks, units):
+            place[t] = m
+    return place, tc
+
+
+def _worker(rank, world, port, n_graphs, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from poseidon_amd import batch
+    mine = batch.shard(n_graphs, world, rank)
+    rows, costs = [], []
+    for b in mine:
+        p, c = _oracle_placements(0, 1 + b, 12, 60)
+        rows.append(p)
+        costs.append(c)
+    local = torch.from_numpy(np.stack(rows)) if rows else torch.empty((0, 60), dtype=torch.int32)
+    allp = batch.all_gather_placements(local, n_graphs, world, rank)
+    allc = batch.all_gather_costs(costs, n_graphs, world, rank)
+    if rank == 0:
+        q.put((allp.numpy(), allc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_graphs", [5, 4])
+def test_two_rank_gather_matches_single_process(n_graphs):
+    from poseidon_amd import batch
+    assert batch.shard(5, 2, 0) == [0, 2, 4] and batch.shard(5, 2, 1) == [1, 3]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_graphs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    allp, allc = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for b in range(n_graphs):
+        p, c = _oracle_placements(0, 1 + b, 12, 60)
+        assert np.array_equal(allp[b], p), b
+        assert allc[b] == c
+
+
+def test_single_rank_passthrough():
+    from poseidon_amd import batch
+    local = torch.arange(12, dtype=torch.int32).view(3, 4)
+    assert torch.equal(batch.all_gather_placements(local, 3, 1, 0), local)
+    assert batch.all_gather_costs([5, 6, 7], 3, 1, 0) == [5, 6, 7]

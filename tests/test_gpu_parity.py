@@ -1,0 +1,223 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs and against the committed golden costs.  Integer work: every
+comparison is bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import poseidon_amd as pa
+from poseidon_amd import _lib
+from oracle import capi, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "psn_synth_v1.json")
+
+
+def _gold(cfg, seed):
+    return [e for e in json.load(open(GOLD))["entries"] if e["config"] == cfg and e["seed"] == seed][0]
+
+
+@pytest.fixture(scope="module")
+def solver():
+    with pa.Solver(device=0) as s:
+        yield s
+
+
+def random_graph(rng, n, m, maxcap=5, maxcost=20, neg=False):
+    tail = rng.integers(0, n, m)
+    head = rng.integers(0, n, m)
+    keep = tail != head
+    tail, head = tail[keep], head[keep]
+    m = tail.shape[0]
+    cap = rng.integers(1, maxcap + 1, m)
+    cost = rng.integers(0, maxcost + 1, m)
+    if neg:
+        pi = rng.integers(0, 10, n)
+        cost = cost + pi[tail] - pi[head]
+    f = rng.integers(0, cap + 1)
+    supply = np.zeros(n, np.int64)
+    np.add.at(supply, tail, f)
+    np.add.at(supply, head, -f)
+    return synth.graph_from_arcs(n, tail, head, cap, cost, supply)
+
+
+def solve_and_certify(s, g):
+    s.upload_csr(g.n, g.row_off, g.head, g.cap, g.cost, g.rev, g.supply)
+    r = s.solve()
+    resid = s.residual()
+    price = s.prices()
+    crc, ctc, _ = capi.check(g, resid, price)
+    assert crc == 0, f"certificate failed with code {crc}"
+    assert ctc == r.total_cost
+    assert capi.check_eps(g, resid, price, 1) == 0
+    flow = s.flow()
+    assert np.array_equal(flow, g.cap - resid)
+    return r
+
+
+def test_random_generic_graphs_vs_ssp(solver):
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        n = int(rng.integers(2, 80))
+        g = random_graph(rng, n, int(rng.integers(1, 8 * n)), neg=trial % 4 == 0)
+        r = solve_and_certify(solver, g)
+        rc, tc, _, _ = capi.ssp(g)
+        assert rc == 0 and tc == r.total_cost, (trial, tc, r.total_cost)
+
+
+def test_random_graphs_with_hubs_and_large_caps(solver):
+    """Star-like graphs: a few vertices above the 1024-arc item size, large capacities."""
+    rng = np.random.default_rng(9)
+    for trial in range(4):
+        n = 600
+        hubs = rng.integers(0, n, 3)
+        m = 9000
+        tail = np.where(rng.random(m) < 0.7, hubs[rng.integers(0, 3, m)], rng.integers(0, n, m))
+        head = rng.integers(0, n, m)
+        keep = tail != head
+        tail, head = tail[keep], head[keep]
+        cap = rng.integers(1, 1000, tail.shape[0])
+        cost = rng.integers(0, 5000, tail.shape[0])
+        f = rng.integers(0, cap + 1)
+        supply = np.zeros(n, np.int64)
+        np.add.at(supply, tail, f)
+        np.add.at(supply, head, -f)
+        g = synth.graph_from_arcs(n, tail, head, cap, cost, supply)
+        assert (np.diff(g.row_off) > 1024).any()
+        r = solve_and_certify(solver, g)
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        assert rc == 0 and tc == r.total_cost
+
+
+def test_trivial_and_edge_cases(solver):
+    # all supplies zero: nothing to route
+    g = synth.graph_from_arcs(3, [0, 1], [1, 2], [2, 2], [1, 1], [0, 0, 0])
+    assert solve_and_certify(solver, g).total_cost == 0
+    # single arc
+    g = synth.graph_from_arcs(2, [0], [1], [5], [7], [3, -3])
+    assert solve_and_certify(solver, g).total_cost == 21
+    # no arcs at all, no supply
+    g = synth.graph_from_arcs(4, [], [], [], [], [0, 0, 0, 0])
+    assert solve_and_certify(solver, g).total_cost == 0
+    # parallel arcs of different cost: cheapest first
+    g = synth.graph_from_arcs(2, [0, 0, 0], [1, 1, 1], [1, 1, 1], [5, 1, 3], [2, -2])
+    assert solve_and_certify(solver, g).total_cost == 4
+
+
+def test_error_codes(solver):
+    lib = pa.load_library()
+    # infeasible: supply that cannot leave
+    g = synth.graph_from_arcs(3, [0], [1], [1], [1], [0, -1, 1])
+    solver.upload_csr(g.n, g.row_off, g.head, g.cap, g.cost, g.rev, g.supply)
+    with pytest.raises(pa.PsnError) as ei:
+        solver.solve()
+    assert ei.value.code == _lib.PSN_EINFEASIBLE
+    # supplies that do not balance are rejected at upload
+    with pytest.raises(pa.PsnError) as ei:
+        solver.upload_csr(2, np.array([0, 1, 2]), [1, 0], [1, 0], [1, -1], [1, 0], [1, 0])
+    assert ei.value.code == _lib.PSN_EINFEASIBLE
+    # malformed CSR: rev not an involution
+    with pytest.raises(pa.PsnError) as ei:
+        solver.upload_csr(2, np.array([0, 1, 2]), [1, 0], [1, 0], [1, -1], [0, 0], [1, -1])
+    assert ei.value.code == _lib.PSN_EINVAL
+    # costs that would overflow int64 prices
+    big = synth.graph_from_arcs(3, [0, 1], [1, 2], [1, 1], [2**31 - 1, 2**31 - 1], [1, 0, -1])
+    n = 3_000_000
+    with pytest.raises(pa.PsnError) as ei:
+        row = np.zeros(n + 1, np.int64); row[1:] = 2; row[2:] = 4
+        solver.upload_csr(n, row, big.head, big.cap, big.cost, big.rev, np.zeros(n, np.int64))
+    assert ei.value.code in (_lib.PSN_EOVERFLOW, _lib.PSN_EINVAL)
+    assert lib.psn_last_error(solver._ctx)
+
+
+@pytest.mark.parametrize("cfg,seed", [(0, 1), (0, 2), (0, 3), (1, 1), (1, 2)])
+def test_synthetic_clusters_vs_golden_and_oracle(solver, cfg, seed):
+    cl = pa.synth_cluster(cfg, seed)
+    net = pa.build_network(cl)
+    solver.upload(net)
+    solver.eval_costs(cl, net)
+    # K1 parity: priced arcs equal the oracle's cost model bit for bit
+    og = synth.build_graph(synth.make_cluster(cfg, seed))
+    cost, ocap = solver.costs()
+    assert np.array_equal(cost, og.cost) and np.array_equal(ocap, og.cap)
+    r = solver.solve()
+    gold = _gold(cfg, seed)
+    assert r.total_cost == gold["optimal_cost"]
+    resid, price = solver.residual(), solver.prices()
+    assert capi.check(og, resid, price)[:2] == (0, r.total_cost)
+    # K5: every placed task sits on a machine that its class can use, within slot capacity
+    place = solver.placements()
+    N, K = cl.layout.n_machines, cl.layout.k_slots
+    placed = place >= 0
+    assert placed.sum() == int((og.cap - resid)[og.fwd_pos[:cl.layout.n_tasks]].sum())  # flow on task->class arcs
+    load = np.bincount(place[placed], minlength=N)
+    assert load.max() <= cl.slots
+    c3, cap3 = synth.eval_costs(synth.make_cluster(cfg, seed))
+    per = {}
+    for t in np.nonzero(placed)[0]:
+        key = (int(cl.task_class[t]), int(place[t]))
+        per[key] = per.get(key, 0) + 1
+    for (e, m), cnt in per.items():
+        assert cnt <= int(cap3[e, m].sum()), "more tasks of a class on a machine than fit"
+    # placements reproduce the objective: k tasks of class e on machine m use its k cheapest slots
+    total = (~placed).sum() * synth.C_UNSCHED + sum(int(np.sort(c3[e, m][cap3[e, m] > 0])[:cnt].sum()) for (e, m), cnt in per.items())
+    assert total == r.total_cost
+
+
+def test_full_size_network_certificate():
+    """10k machines / 100k pods: cost equals the golden value and the flow carries an
+    optimality certificate (size-independent check, no CPU re-solve needed)."""
+    cl = pa.synth_cluster(2, 1)
+    net = pa.build_network(cl)
+    with pa.Solver(device=0) as s:
+        s.upload(net)
+        s.eval_costs(cl, net)
+        r = s.solve()
+        resid, price = s.residual(), s.prices()
+        cost, ocap = s.costs()
+        place = s.placements()
+        # idempotence: a second cold solve gives the same cost
+        s.eval_costs(cl, net)
+        r2 = s.solve()
+    assert r.total_cost == _gold(2, 1)["optimal_cost"] == r2.total_cost
+    og = synth.build_graph(synth.make_cluster(2, 1))
+    assert np.array_equal(cost, og.cost) and np.array_equal(ocap, og.cap)
+    assert capi.check(og, resid, price)[:2] == (0, r.total_cost)
+    assert capi.check_eps(og, resid, price, 1) == 0
+    routed = int((og.cap - resid)[og.fwd_pos[:100000]].sum())  # flow on task -> class arcs
+    assert int((place >= 0).sum()) == routed
+    assert np.bincount(place[place >= 0], minlength=10000).max() <= cl.slots
+
+
+def test_eager_and_graph_agree():
+    cl = pa.synth_cluster(0, 2)
+    net = pa.build_network(cl)
+    costs = []
+    for eager in (False, True):
+        with pa.Solver(device=0, eager=eager) as s:
+            s.upload(net)
+            s.eval_costs(cl, net)
+            costs.append(s.solve().total_cost)
+    assert costs[0] == costs[1] == _gold(0, 2)["optimal_cost"]
+
+
+def test_warm_start_after_capacity_change(solver):
+    """Take machines out (machine->sink capacity 0) and re-solve warm: the result equals a
+    cold solve of the changed network."""
+    cl = pa.synth_cluster(0, 3)
+    net = pa.build_network(cl)
+    solver.upload(net)
+    solver.eval_costs(cl, net)
+    solver.solve()
+    N, E, K = cl.layout.n_machines, cl.layout.n_classes, cl.layout.k_slots
+    gone = np.arange(0, N, 7)
+    arcs = np.array([net.row_off[1 + m] + E * K for m in gone], np.int64)  # machine -> sink
+    solver.update_caps(arcs, np.zeros(arcs.shape[0], np.int32))
+    rw = solver.solve(warm_start=True)
+    og = synth.build_graph(synth.make_cluster(0, 3))
+    og.cap[arcs] = 0
+    rc, tc, _, _, _ = capi.cost_scaling(og)
+    assert rc == 0 and rw.total_cost == tc
+    assert capi.check(og, solver.residual(), solver.prices())[:2] == (0, tc)

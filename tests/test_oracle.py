@@ -1,0 +1,127 @@
+"""CPU tests of the oracle: the two C solvers, the certificate and the numpy builder agree
+with each other, with the committed golden vectors (cross-checked once against networkx
+network_simplex, see tests/golden/make_golden.py) and on adversarial small cases."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import capi, synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "psn_synth_v1.json")
+
+
+def _golden():
+    with open(GOLD) as f:
+        return json.load(f)["entries"]
+
+
+def random_graph(rng, n, m, maxcap=5, maxcost=20, neg=False):
+    tail = rng.integers(0, n, m)
+    head = rng.integers(0, n, m)
+    keep = tail != head
+    tail, head = tail[keep], head[keep]
+    m = tail.shape[0]
+    cap = rng.integers(1, maxcap + 1, m)
+    cost = rng.integers(0, maxcost + 1, m)
+    if neg:  # negative arc costs but no negative cycle: shift by a random potential
+        pi = rng.integers(0, 10, n)
+        cost = cost + pi[tail] - pi[head]
+    f = rng.integers(0, cap + 1)
+    supply = np.zeros(n, np.int64)
+    np.add.at(supply, tail, f)
+    np.add.at(supply, head, -f)
+    return synth.graph_from_arcs(n, tail, head, cap, cost, supply)
+
+
+def test_splitmix_known_answers():
+    # splitmix64 reference outputs for seed 0 (Vigna's test vector)
+    out = synth.splitmix64_stream(0, 3)
+    assert [int(x) for x in out] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+
+
+def test_cost_model_numpy_vs_c():
+    cl = synth.make_cluster(0, 2)
+    c1, p1 = synth.eval_costs(cl)
+    c2, p2 = capi.eval_costs(cl)
+    assert np.array_equal(c1, c2) and np.array_equal(p1, p2)
+    # fits: capacity 1 exactly for the first `fit` slots, convex cost in k
+    assert (np.diff(c1, axis=2) >= 0).all()
+    assert (np.diff(p1, axis=2) <= 0).all()
+    # a request larger than what is left never fits (the reference's e2e expectation that an
+    # over-committed pod stays pending, /root/reference/test/e2e/poseidon_integration.go:310-408)
+    free_cpu = cl.cap_cpu - cl.used_cpu
+    e_big = np.argmax(cl.req_cpu)
+    assert (p1[e_big][free_cpu < cl.req_cpu[e_big]] == 0).all()
+
+
+@pytest.mark.parametrize("entry", [e for e in _golden() if e["config"] == 0], ids=lambda e: f"c{e['config']}s{e['seed']}")
+def test_golden_small(entry):
+    cl = synth.make_cluster(entry["config"], entry["seed"])
+    g = synth.build_graph(cl)
+    assert (g.n, g.m) == (entry["n"], entry["m"])
+    assert "%016x" % capi.csr_checksum(g) == entry["csr_fnv1a64"]
+    rc, tc, cap, pot = capi.ssp(g)
+    assert rc == 0 and tc == entry["optimal_cost"] == entry["networkx_network_simplex"]
+    assert capi.check(g, cap)[:2] == (0, tc)
+    rc, tc2, cap2, price, st = capi.cost_scaling(g)
+    assert rc == 0 and tc2 == tc
+    assert capi.check(g, cap2, price)[:2] == (0, tc)
+    assert capi.check_eps(g, cap2, price, 1) == 0
+
+
+def test_golden_c1_cost_scaling():
+    entry = [e for e in _golden() if e["config"] == 1 and e["seed"] == 1][0]
+    g = synth.build_graph(synth.make_cluster(1, 1))
+    assert "%016x" % capi.csr_checksum(g) == entry["csr_fnv1a64"]
+    rc, tc, cap, price, st = capi.cost_scaling(g)
+    assert rc == 0 and tc == entry["optimal_cost"]
+    assert capi.check(g, cap, price)[:2] == (0, tc)
+
+
+def test_random_graphs_ssp_equals_cost_scaling():
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        n = int(rng.integers(2, 40))
+        g = random_graph(rng, n, int(rng.integers(1, 6 * n)), neg=trial % 3 == 0)
+        rc1, tc1, cap1, _ = capi.ssp(g)
+        rc2, tc2, cap2, price, _ = capi.cost_scaling(g)
+        assert rc1 == 0 and rc2 == 0 and tc1 == tc2, (trial, rc1, rc2, tc1, tc2)
+        assert capi.check(g, cap1)[0] == 0 and capi.check(g, cap2, price)[0] == 0
+
+
+def test_certificate_rejects_wrong_answers():
+    g = synth.build_graph(synth.make_cluster(0, 1, 20, 100))
+    rc, tc, cap, price, _ = capi.cost_scaling(g)
+    assert capi.check(g, cap, price)[0] == 0
+    # break conservation: cancel one unit of flow on one arc only
+    a = int(np.nonzero((g.cap - cap) > 0)[0][0])
+    bad = cap.copy(); bad[a] += 1; bad[g.rev[a]] -= 1
+    assert capi.check(g, bad)[0] == 1
+    # bounds: negative residual capacity
+    bad = cap.copy(); bad[a] = -1
+    assert capi.check(g, bad)[0] == 2
+    # feasible but not optimal: the all-unscheduled flow
+    N, E, J, P = g.n_machines, g.n_ec, g.n_jobs, g.n_pods
+    sub = cap.copy(); sub[:] = g.cap
+    row = g.row_off
+    for t in range(P):
+        v = 1 + N + E + J + t
+        a2 = row[v] + 1                      # task -> unsched
+        sub[a2] -= 1; sub[g.rev[a2]] += 1
+        j = g.head[a2]
+        a3 = row[j + 1] - 1                  # unsched -> sink
+        sub[a3] -= 1; sub[g.rev[a3]] += 1
+    rc_sub, cost_sub, _ = capi.check(g, sub)
+    assert rc_sub == 3 and cost_sub == P * synth.C_UNSCHED
+
+
+def test_infeasible_and_trivial():
+    # supply with no outgoing capacity
+    g = synth.graph_from_arcs(3, [0], [1], [1], [1], [0, -1, 1])
+    assert capi.ssp(g)[0] == -4
+    # empty flow: all supplies zero
+    g = synth.graph_from_arcs(3, [0, 1], [1, 2], [2, 2], [1, 1], [0, 0, 0])
+    assert capi.ssp(g)[:2] == (0, 0)
+    assert capi.cost_scaling(g)[:2] == (0, 0)
