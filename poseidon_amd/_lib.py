@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpsn.so")
+LIB_PATH = os.environ.get("PSN_LIB") or os.path.join(_HERE, "libpsn.so")  # PSN_LIB: A/B builds during tuning
 
 PSN_OK = 0
 PSN_EINVAL, PSN_ENOMEM, PSN_EDEVICE, PSN_EINFEASIBLE = -1, -2, -3, -4

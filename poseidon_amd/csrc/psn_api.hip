@@ -91,7 +91,8 @@ void free_graph_buffers(psn_ctx *c) {
 int enqueue_replay(psn_ctx *c, hipStream_t s) {
     const DevGraph &g = c->g;
     int launches = 0;
-    const int gv = std::max(1, std::min(kGrid, (g.n + kBlock - 1) / kBlock));  // vertex sweeps
+    const int gv = std::max(1, std::min(kGrid, (g.n + kBlock * kVpt - 1) / (kBlock * kVpt)));  // vertex sweeps
+    const int gv1 = std::max(1, std::min(kGrid, (g.n + kBlock - 1) / kBlock));
     const bool timed = (c->cfg.flags & PSN_CFG_KTIME) && !c->gexec;
     auto mark = [&](int cls, bool begin) {
         if (!timed) return;
@@ -116,7 +117,7 @@ int enqueue_replay(psn_ctx *c, hipStream_t s) {
     L(PSN_KT_OTHER, k_gu_init, gv, g);
     for (int k = 0; k < kGuIters; ++k) L(PSN_KT_GU_EXPAND, k_gu_expand, kGrid, g, k);
     hipLaunchKernelGGL(k_mid, dim3(1), dim3(1), 0, s, g, kGuIters); ++launches;
-    L(PSN_KT_OTHER, k_gu_apply, gv, g);
+    L(PSN_KT_OTHER, k_gu_apply, gv1, g);
     L(PSN_KT_RELABEL, k_relabel_compact, gv, g, 0, 0);
     for (int k = 0; k < c->rounds; ++k) {
         L(PSN_KT_PUSH, k_push, kGrid, g, k);
@@ -228,7 +229,7 @@ void psn_destroy(psn_ctx *c) {
 int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, const int32_t *head, const int32_t *cap,
                    const int32_t *cost, const int32_t *rev, const int64_t *supply) {
     if (!c) return PSN_EINVAL;
-    if (n <= 0 || m2 < 0 || m2 >= (int64_t)0x7FFFFFF0 || !row_off || !supply || (m2 > 0 && (!head || !cap || !cost || !rev)))
+    if (n <= 0 || n >= kMaxVertices || m2 < 0 || m2 >= (int64_t)0x7FFFFFF0 || !row_off || !supply || (m2 > 0 && (!head || !cap || !cost || !rev)))
         return fail(c, PSN_EINVAL, "null or out-of-range argument");
     // ---- validate on the host: a malformed graph must never reach a kernel
     if (row_off[0] != 0 || row_off[n] != m2) return fail(c, PSN_EINVAL, "row_off[0] != 0 or row_off[n] != m2");

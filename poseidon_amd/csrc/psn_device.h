@@ -13,9 +13,12 @@ typedef long long i64;
 constexpr int kBlock = 256;      // threads per workgroup (4 waves)
 constexpr int kGrid = 1024;      // workgroups per sweep launch: 16 waves per CU on 256 CUs
 constexpr unsigned kLowMax = 4;  // degree <= kLowMax: one lane per vertex
-constexpr unsigned kWSeg = 1024; // arcs per wave work item; larger vertices are split into several items
+constexpr unsigned kStep = 576;  // arcs per wave step: 8 consecutive per lane + one strided
+constexpr unsigned kWSeg = 2 * kStep;  // arcs per wave work item; larger vertices are split into several items
 constexpr unsigned kMedMax = kWSeg;  // degree <= kMedMax: the whole vertex is one wave item
-constexpr unsigned kQCap = 512;  // entries per per-wave LDS frontier staging queue
+constexpr unsigned kQCap = 256;  // entries per per-wave LDS frontier staging queue
+constexpr int kVpt = 4;          // vertices per thread in the vertex sweeps
+constexpr int kMaxVertices = 1 << 28;  // lane items pack the degree above bit 28
 constexpr int kClsLow = 0, kClsMed = 1, kClsHigh = 2;  // vertex classes by degree
 constexpr int kClsSeg = 1;       // counter slot of the (vertex, segment) item lists (slot 0: lane list)
 constexpr int kMaxHubs = 128;    // highest-degree vertices whose atomics are pre-combined in LDS per workgroup
@@ -60,10 +63,10 @@ struct DevGraph {
     int *cap, *rcap;
     i64 *price, *excess, *cand, *dist;
     unsigned *fstamp;
-    int *list_low[2];   // active vertices of degree <= kLowMax (one lane each)
-    int2 *list_seg[2];  // active (vertex, segment) wave items
-    int *fr_low[3];     // global-update frontier, same split, triple buffered
-    int2 *fr_seg[3];
+    int2 *list_low[2];  // active vertices of degree <= kLowMax (one lane each)
+    int4 *list_seg[2];  // active wave items (vertex, arc range, flags)
+    int2 *fr_low[3];    // global-update frontier, same split, triple buffered
+    int4 *fr_seg[3];
     unsigned long long *tally;
     Ctrl *ctrl;
     int4 *dbg;          // optional launch trace (kind, k, lane-list size, item-list size); null when off

@@ -78,48 +78,47 @@ __device__ __forceinline__ void tally_flush(const DevGraph &g, Tally &t) {
     }
 }
 
-__device__ __forceinline__ unsigned nseg_of(const DevGraph &g, int v) {
-    return (g.row[v + 1] - g.row[v] + kWSeg - 1) / kWSeg;
+// ------------------------------------------------------------------------ work items
+// Lane item  (degree <= kLowMax): int2 { v | degree << 28, first arc }.
+// Wave item  (everything else):   int4 { v, first arc, end arc, flags } covering at most
+// kWSeg arcs; flags bit 0 = the item is the whole vertex ("solo").  Items carry their arc
+// range so that a sweep does not pay a dependent row-offset load before it can stream.
+__device__ __forceinline__ int2 low_item(int v, unsigned r0, unsigned r1) { return make_int2(v | (int)((r1 - r0) << 28), (int)r0); }
+__device__ __forceinline__ int4 solo_item(int v, unsigned r0, unsigned r1) { return make_int4(v, (int)r0, (int)r1, 1); }
+// A vertex larger than one item: its segments, starting at a per-round rotated one so that
+// vertices with common neighbours do not all begin at the same arcs.
+__device__ __forceinline__ void append_split(unsigned *cnt, int4 *segl, int v, unsigned r0, unsigned r1, unsigned rot) {
+    const unsigned nseg = (r1 - r0 + kWSeg - 1) / kWSeg;
+    const unsigned base = aadd32(&cnt[kClsSeg], nseg);
+    unsigned sg = rot % nseg;
+    for (unsigned s = 0; s < nseg; ++s) {
+        const unsigned a = r0 + sg * kWSeg;
+        segl[base + s] = make_int4(v, (int)a, (int)min(r1, a + kWSeg), 0);
+        if (++sg == nseg) sg = 0;
+    }
+}
+
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { unsigned y = __shfl_up(x, d); if (l >= d) x += y; }
+    return x;
 }
 
 // ------------------------------------------------------- active-list compaction (K4)
-// Appends the vertices flagged by `take` to the work lists: one ballot per list, one
-// atomic per wave per non-empty list, slots by popcount prefix.  Vertices of degree
-// <= kLowMax go to the lane list; all others become (vertex, segment) wave items.
-__device__ __forceinline__ void wave_append(const DevGraph &g, unsigned *cnt, int *lowl, int2 *segl, bool take, int v, int cls) {
-    const unsigned long long lt = lanemask_lt();
-    unsigned long long m = __ballot(take && cls == kClsLow);
-    if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        unsigned base = 0;
-        if (lane_id() == leader) base = aadd32(&cnt[kClsLow], (unsigned)__popcll(m));
-        base = __shfl(base, leader);
-        if (take && cls == kClsLow) lowl[base + __popcll(m & lt)] = v;
-    }
-    m = __ballot(take && cls == kClsMed);
-    if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        unsigned base = 0;
-        if (lane_id() == leader) base = aadd32(&cnt[kClsSeg], (unsigned)__popcll(m));
-        base = __shfl(base, leader);
-        if (take && cls == kClsMed) segl[base + __popcll(m & lt)] = make_int2(v, 0);
-    }
-    if (take && cls == kClsHigh) {  // rare: a handful of vertices own most arcs
-        const unsigned nseg = nseg_of(g, v);
-        const unsigned base = aadd32(&cnt[kClsSeg], nseg);
-        for (unsigned s = 0; s < nseg; ++s) segl[base + s] = make_int2(v, (int)s);
-    }
-}
-
-// Same as wave_append with one atomic per workgroup per list: used by the vertex sweeps,
-// where every wave would otherwise hit the same two counters.  Uniform call sites only.
-__device__ __forceinline__ void block_append(const DevGraph &g, unsigned *cnt, int *lowl, int2 *segl, bool take, int v, int cls,
+// Vertex sweep helper: each thread brings VPT vertices (take[i], class, arc range); lane
+// and wave items are numbered by a popcount-style prefix inside the wave, waves are
+// chained through LDS, and the workgroup takes its slots with one atomic per list.
+template <int VPT>
+__device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *segl, const bool (&take)[VPT], const int (&v)[VPT],
+                                             const int (&cls)[VPT], const unsigned (&r0)[VPT], const unsigned (&r1)[VPT], unsigned rot,
                                              unsigned (*lds)[kBlock / 64 + 1]) {
-    const unsigned long long lt = lanemask_lt();
-    const unsigned long long mlow = __ballot(take && cls == kClsLow);
-    const unsigned long long mseg = __ballot(take && cls == kClsMed);
+    unsigned nl = 0, ns = 0;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) { nl += take[i] && cls[i] == kClsLow; ns += take[i] && cls[i] == kClsMed; }
+    const unsigned il = wave_incl_scan_u32(nl), is = wave_incl_scan_u32(ns);
     const int w = threadIdx.x >> 6;
-    if (lane_id() == 0) { lds[0][w] = (unsigned)__popcll(mlow); lds[1][w] = (unsigned)__popcll(mseg); }
+    if (lane_id() == 63) { lds[0][w] = il; lds[1][w] = is; }
     __syncthreads();
     if (threadIdx.x < 2) {
         unsigned tot = 0;
@@ -127,17 +126,14 @@ __device__ __forceinline__ void block_append(const DevGraph &g, unsigned *cnt, i
         lds[threadIdx.x][kBlock / 64] = tot ? aadd32(&cnt[threadIdx.x == 0 ? kClsLow : kClsSeg], tot) : 0u;
     }
     __syncthreads();
-    if (take && cls != kClsHigh) {
-        const int c = cls == kClsLow ? 0 : 1;
-        unsigned pos = lds[c][kBlock / 64];
-        for (int i = 0; i < w; ++i) pos += lds[c][i];
-        if (c == 0) lowl[pos + __popcll(mlow & lt)] = v;
-        else segl[pos + __popcll(mseg & lt)] = make_int2(v, 0);
-    }
-    if (take && cls == kClsHigh) {
-        const unsigned nseg = nseg_of(g, v);
-        const unsigned base = aadd32(&cnt[kClsSeg], nseg);
-        for (unsigned s = 0; s < nseg; ++s) segl[base + s] = make_int2(v, (int)s);
+    unsigned pl = lds[0][kBlock / 64] + il - nl, ps = lds[1][kBlock / 64] + is - ns;
+    for (int i = 0; i < w; ++i) { pl += lds[0][i]; ps += lds[1][i]; }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        if (!take[i]) continue;
+        if (cls[i] == kClsLow) lowl[pl++] = low_item(v[i], r0[i], r1[i]);
+        else if (cls[i] == kClsMed) segl[ps++] = solo_item(v[i], r0[i], r1[i]);
+        else append_split(cnt, segl, v[i], r0[i], r1[i], rot ^ (unsigned)v[i] * 0x9E3779B9u);  // rare: hubs
     }
     __syncthreads();
 }
@@ -168,74 +164,79 @@ __device__ __forceinline__ void hub_flush_push(const DevGraph &g, const HubAcc &
     }
 }
 
-// Eight consecutive int32 per lane, two 16-byte loads when fully inside [.., r1).
-__device__ __forceinline__ void load8(const int *p, unsigned a0, unsigned r1, int (&x)[8]) {
-    if (a0 + 7 < r1) {
+// One step of a wave item covers up to kStep = 576 arcs starting at h: lane p owns the 8
+// consecutive arcs h + 8p .. h + 8p + 7 (two 16-byte loads per array) and arc h + 512 + p.
+// The ninth arc lets a 513-arc row (64 classes x 8 slots + the sink arc of a machine) go
+// through in one step.  Slot j of a lane: arc index arc9(a0, at, j).
+__device__ __forceinline__ unsigned arc9(unsigned a0, unsigned at, int j) { return j < 8 ? a0 + (unsigned)j : at; }
+__device__ __forceinline__ void load9(const int *p, unsigned a0, unsigned lim8, unsigned at, unsigned limt, int (&x)[9]) {
+    if (a0 + 7 < lim8) {
         const int4u lo = *reinterpret_cast<const int4u *>(p + a0);
         const int4u hi = *reinterpret_cast<const int4u *>(p + a0 + 4);
         x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = a0 + j < r1 ? p[a0 + j] : 0;
+        for (int j = 0; j < 8; ++j) x[j] = a0 + j < lim8 ? p[a0 + j] : 0;
     }
+    x[8] = at < limt ? p[at] : 0;
+}
+__device__ __forceinline__ unsigned count9(unsigned a0, unsigned lim8, unsigned at, unsigned limt) {
+    return (a0 < lim8 ? min(8u, lim8 - a0) : 0u) + (at < limt ? 1u : 0u);
 }
 
 // --------------------------------------------------------------------------- pushes
-// One unit of push bookkeeping: the caller owns arc a (tail u); r = rev[a] is only
-// written here because (v,u) cannot be admissible while (u,v) is.
-__device__ __forceinline__ void do_push(const DevGraph &g, const HubAcc &hb, unsigned a, int v, int cap_before, i64 d, i64 pu, i64 cS) {
-    const int r = g.rev[a];
-    const int na = cap_before - (int)d;
-    const int nr = g.cap[r] + (int)d;
-    g.cap[a] = na;
-    g.cap[r] = nr;
-    g.rcap[a] = nr;
-    g.rcap[r] = na;
-    const int h = g.hub_of[v];
-    const i64 key = pu + cS;  // key of the new residual arc (v,u): price[u] - cost(v,u)
-    if (h >= 0) { lds_add(&hb.add[h], d); lds_max(&hb.ext[h], key); }
-    else { aadd64(&g.excess[v], d); amax64(&g.cand[v], key); }
-}
-
-// Low-degree vertex: one lane walks its arcs.
-__device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, int u, i64 S, Tally &t) {
-    const unsigned r0 = g.row[u], r1 = g.row[u + 1];
+// Low-degree vertex: one lane, all loads of its (at most kLowMax) arcs issued together.
+__device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, int2 it, i64 S, Tally &t) {
+    const int u = it.x & 0x0FFFFFFF;
+    const unsigned deg = (unsigned)it.x >> 28, r0 = (unsigned)it.y;
     const i64 pu = g.price[u];
     const i64 e0 = g.excess[u];
-    i64 e = e0, best = kNegInf;
+    int cp[kLowMax], hd[kLowMax], cs[kLowMax];
+#pragma unroll
+    for (unsigned j = 0; j < kLowMax; ++j) {
+        const bool ok = j < deg;
+        cp[j] = ok ? g.cap[r0 + j] : 0; hd[j] = ok ? g.head[r0 + j] : 0; cs[j] = ok ? g.cost[r0 + j] : 0;
+    }
+    i64 key[kLowMax];
+#pragma unroll
+    for (unsigned j = 0; j < kLowMax; ++j) key[j] = cp[j] > 0 ? g.price[hd[j]] - (i64)cs[j] * S : kNegInf;
     t.c[kTallyVisits]++;
-    for (unsigned a = r0; a < r1; ++a) {
-        int cp = g.cap[a];
-        t.c[kTallyScans]++;
-        if (cp <= 0) continue;
-        const int v = g.head[a];
-        const i64 cS = (i64)g.cost[a] * S;
-        const i64 key = g.price[v] - cS;
-        if (key > pu && e > 0) {
-            i64 d = e < cp ? e : cp;
-            do_push(g, hb, a, v, cp, d, pu, cS);
-            e -= d; cp -= (int)d;
+    t.c[kTallyScans] += deg;
+    i64 e = e0, best = kNegInf;
+#pragma unroll
+    for (unsigned j = 0; j < kLowMax; ++j) {
+        if (key[j] > pu && e > 0) {
+            const i64 d = e < cp[j] ? e : cp[j];
+            const unsigned a = r0 + j;
+            const int r = g.rev[a];
+            const int na = cp[j] - (int)d, nr = g.cap[r] + (int)d;
+            g.cap[a] = na; g.cap[r] = nr; g.rcap[a] = nr; g.rcap[r] = na;
+            const int h = g.hub_of[hd[j]];
+            const i64 kr = pu + (i64)cs[j] * S;
+            if (h >= 0) { lds_add(&hb.add[h], d); lds_max(&hb.ext[h], kr); }
+            else { aadd64(&g.excess[hd[j]], d); amax64(&g.cand[hd[j]], kr); }
+            e -= d; cp[j] = na;
             t.c[kTallyPushes]++;
         }
-        if (cp > 0 && key > best) best = key;
+        if (cp[j] > 0 && key[j] > best) best = key[j];
     }
     if (best > kNegInf) amax64(&g.cand[u], best);
     if (e != e0) aadd64(&g.excess[u], e - e0);
 }
 
-// One wave item: up to kWSeg arcs of vertex u, 512 per step (8 per lane, coalesced 16-byte
-// loads).  A vertex that fits one item keeps its excess in a register; a vertex split
-// over several items has its waves claim what they want to push from excess[u] and hand
-// back what was not granted.  `rot` permutes which lane owns which 8 arcs, so that the
-// prefix order (= who gets the excess first) changes from round to round.
-__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int u, unsigned seg, bool solo, i64 S, unsigned rot, Tally &t) {
+// One wave item.  A solo vertex keeps its excess in a register; a vertex split over
+// several items has its waves claim what they want to push from excess[u] and hand back
+// what was not granted.  `rot` permutes which lane owns which arcs, so that the prefix
+// order (= who gets the excess first) changes from round to round.
+__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int4 it, i64 S, unsigned rot, Tally &t) {
     const int lane = lane_id();
-    const unsigned r0 = g.row[u] + seg * kWSeg;
-    const unsigned r1 = min(g.row[u + 1], r0 + kWSeg);
+    const int u = it.x;
+    const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
+    const bool solo = it.w & 1;
     const i64 pu = g.price[u];
-    if (lane == 0) t.c[kTallyVisits]++;
     i64 e0 = __hip_atomic_load(&g.excess[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     e0 = __shfl(e0, 0);
+    if (lane == 0) t.c[kTallyVisits]++;
     if (e0 <= 0) {  // drained by the vertex's other items: this one stays unscanned
         if (lane == 0) amax64(&g.cand[u], kInf);
         return;
@@ -243,21 +244,18 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
     i64 e = e0, best = kNegInf;
     bool incomplete = false;
     const unsigned plane = (unsigned)(lane + rot) & 63u;
-    for (unsigned h = r0; h < r1; h += 512) {
-        const unsigned a0 = h + plane * 8;
-        int cp[8], hd[8], cs[8];
-        load8(g.cap, a0, r1, cp);
-        bool anyc = false;
+    for (unsigned h = r0; h < r1; h += kStep) {
+        const unsigned a0 = h + plane * 8, lim8 = min(r1, h + 512), at = h + 512 + plane, limt = min(r1, h + kStep);
+        int cp[9], hd[9], cs[9];
+        load9(g.cap, a0, lim8, at, limt, cp);
+        load9(g.head, a0, lim8, at, limt, hd);
+        load9(g.cost, a0, lim8, at, limt, cs);
+        t.c[kTallyScans] += count9(a0, lim8, at, limt);
+        i64 key[9], want = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) anyc |= cp[j] > 0;
-        if (a0 < r1) t.c[kTallyScans] += min(8u, r1 - a0);
-        if (anyc) { load8(g.head, a0, r1, hd); load8(g.cost, a0, r1, cs); }
-        i64 key[8], want = 0;
+        for (int j = 0; j < 9; ++j) key[j] = cp[j] > 0 ? g.price[hd[j]] - (i64)cs[j] * S : kNegInf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            key[j] = (anyc && cp[j] > 0) ? g.price[hd[j]] - (i64)cs[j] * S : kNegInf;
-            if (key[j] > pu) want += cp[j];
-        }
+        for (int j = 0; j < 9; ++j) if (key[j] > pu) want += cp[j];
         if (__ballot(want > 0)) {
             const i64 incl = wave_incl_scan(want);
             const i64 total = __shfl(incl, 63);
@@ -277,25 +275,26 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
             i64 mine = granted - (incl - want);  // what this lane may push
             if (mine > 0) {
                 // amounts first, then every load of the batch before any dependent store
-                i64 d[8];
+                int d[9];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 9; ++j) {
                     d[j] = 0;
-                    if (key[j] > pu && mine > 0) { d[j] = mine < cp[j] ? mine : cp[j]; mine -= d[j]; }
+                    if (key[j] > pu && mine > 0) { d[j] = (int)(mine < cp[j] ? mine : cp[j]); mine -= d[j]; }
                 }
-                int rv[8], cr[8], hub[8];
+                int rv[9], cr[9], hub[9];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { rv[j] = d[j] > 0 ? g.rev[a0 + j] : 0; hub[j] = d[j] > 0 ? g.hub_of[hd[j]] : -1; }
+                for (int j = 0; j < 9; ++j) { rv[j] = d[j] > 0 ? g.rev[arc9(a0, at, j)] : 0; hub[j] = d[j] > 0 ? g.hub_of[hd[j]] : -1; }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) cr[j] = d[j] > 0 ? g.cap[rv[j]] : 0;
+                for (int j = 0; j < 9; ++j) cr[j] = d[j] > 0 ? g.cap[rv[j]] : 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 9; ++j) {
                     if (d[j] > 0) {
-                        const int na = cp[j] - (int)d[j], nr = cr[j] + (int)d[j];
-                        g.cap[a0 + j] = na; g.cap[rv[j]] = nr; g.rcap[a0 + j] = nr; g.rcap[rv[j]] = na;
+                        const unsigned a = arc9(a0, at, j);
+                        const int na = cp[j] - d[j], nr = cr[j] + d[j];
+                        g.cap[a] = na; g.cap[rv[j]] = nr; g.rcap[a] = nr; g.rcap[rv[j]] = na;
                         const i64 kr = pu + (i64)cs[j] * S;  // key of the new residual arc (v,u)
-                        if (hub[j] >= 0) { lds_add(&hb.add[hub[j]], d[j]); lds_max(&hb.ext[hub[j]], kr); }
-                        else { aadd64(&g.excess[hd[j]], d[j]); amax64(&g.cand[hd[j]], kr); }
+                        if (hub[j] >= 0) { lds_add(&hb.add[hub[j]], (i64)d[j]); lds_max(&hb.ext[hub[j]], kr); }
+                        else { aadd64(&g.excess[hd[j]], (i64)d[j]); amax64(&g.cand[hd[j]], kr); }
                         cp[j] = na;
                         t.c[kTallyPushes]++;
                     }
@@ -303,13 +302,13 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
             }
             if (granted < total || (solo && e == 0)) {  // out of excess
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (cp[j] > 0 && key[j] > best) best = key[j];
-                if (h + 512 < r1) incomplete = true;
+                for (int j = 0; j < 9; ++j) if (cp[j] > 0 && key[j] > best) best = key[j];
+                if (h + kStep < r1) incomplete = true;
                 break;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (cp[j] > 0 && key[j] > best) best = key[j];
+        for (int j = 0; j < 9; ++j) if (cp[j] > 0 && key[j] > best) best = key[j];
     }
     best = wave_max(best);
     if (lane == 0) {
@@ -335,18 +334,14 @@ __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
     hub_init(hb, kNegInf);
     const i64 S = g.scale;
     const unsigned salt = ct->epoch * 64u + (unsigned)k;
-    const int *lowl = g.list_low[k & 1];
-    const int2 *segl = g.list_seg[k & 1];
+    const int2 *lowl = g.list_low[k & 1];
+    const int4 *segl = g.list_seg[k & 1];
     const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
     for (unsigned i = wave; i < nseg; i += nwaves) {
-        const int2 it = segl[i];
-        const unsigned ns = nseg_of(g, it.x);
-        const unsigned h = mix32((unsigned)it.x, salt);
-        // start segment rotated per round so that vertices sharing neighbours do not all
-        // begin at the same ones
-        push_item(g, hb, it.x, ns > 1 ? ((unsigned)it.y + h) % ns : 0u, ns == 1, S, h >> 16, t);
+        const int4 it = segl[i];
+        push_item(g, hb, it, S, mix32((unsigned)it.x, salt) >> 16, t);
     }
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, hb, lowl[i], S, t);
     hub_flush_push(g, hb);
@@ -355,8 +350,9 @@ __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
 }
 
 // Relabel (optional) + rebuild of the active lists for the next round: one sweep over
-// the vertices.  cand[v] is +inf for vertices outside the list, so a vertex that only
-// became active during the push phase is never relabelled on partial information.
+// the vertices, kVpt per thread.  cand[v] is +inf for vertices outside the list, so a
+// vertex that only became active during the push phase is never relabelled on partial
+// information.
 __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, int do_relabel) {
     Ctrl *ct = g.ctrl;
     if (!ct->rounds_on) return;
@@ -366,25 +362,37 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
         if (cnt[kClsLow] + cnt[kClsSeg] == 0) return;  // nothing was active
     }
     const i64 eps = ct->eps;
+    const unsigned rot = mix32(ct->epoch, (unsigned)k);
     Tally t;
     __shared__ unsigned s_app[2][kBlock / 64 + 1];
-    const int nround = (g.n + kBlock - 1) / kBlock * kBlock;
-    for (int v = blockIdx.x * kBlock + threadIdx.x; v < nround; v += gridDim.x * kBlock) {
-        bool act = false;
-        int cls = 0;
-        if (v < g.n) {
-            const i64 e = g.excess[v];
-            act = e > 0;
-            const i64 c = g.cand[v];
-            if (act && do_relabel && c != kInf && c != kNegInf) {
-                const i64 p = g.price[v];
-                if (c <= p) { g.price[v] = c - eps; t.c[kTallyRelabels]++; }
-            }
-            const i64 nc = act ? kNegInf : kInf;
-            if (c != nc) g.cand[v] = nc;
-            cls = g.cls[v];
+    const int span = kBlock * kVpt;
+    for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
+        bool act[kVpt];
+        int v[kVpt], cls[kVpt];
+        unsigned r0[kVpt], r1[kVpt];
+        i64 e[kVpt], c[kVpt], p[kVpt];
+#pragma unroll
+        for (int i = 0; i < kVpt; ++i) {
+            v[i] = base + i * kBlock + (int)threadIdx.x;
+            const bool in = v[i] < g.n;
+            e[i] = in ? g.excess[v[i]] : 0;
+            c[i] = in ? g.cand[v[i]] : kInf;
+            cls[i] = in ? (int)g.cls[v[i]] : 0;
         }
-        block_append(g, ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, s_app);
+#pragma unroll
+        for (int i = 0; i < kVpt; ++i) {
+            act[i] = e[i] > 0;
+            p[i] = (act[i] && do_relabel && c[i] != kInf && c[i] != kNegInf) ? g.price[v[i]] : kNegInf;
+            r0[i] = act[i] ? g.row[v[i]] : 0;
+            r1[i] = act[i] ? g.row[v[i] + 1] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < kVpt; ++i) {
+            if (p[i] != kNegInf && c[i] <= p[i]) { g.price[v[i]] = c[i] - eps; t.c[kTallyRelabels]++; }
+            const i64 nc = act[i] ? kNegInf : kInf;
+            if (v[i] < g.n && c[i] != nc) g.cand[v[i]] = nc;
+        }
+        block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app);
     }
     tally_flush<kTallyRelabels>(g, t);
 }
@@ -453,8 +461,8 @@ __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) {
 // price[v] -= eps*dist[v].  Newly improved vertices are staged in a per-wave LDS queue
 // and flushed to the global frontier in coalesced bursts with one atomic per burst.
 struct WaveQ {
-    int *low;             // LDS staging, kQCap vertex ids
-    int2 *seg;            // LDS staging, kQCap (vertex, segment) items
+    int2 *low;            // LDS staging, kQCap lane items
+    int4 *seg;            // LDS staging, kQCap wave items
     unsigned nlow, nseg;  // wave-uniform fill counts
 };
 template <typename T>
@@ -468,12 +476,6 @@ __device__ __forceinline__ void waveq_flush_one(T *q, unsigned &n, unsigned *cnt
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     n = 0;
 }
-__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { unsigned y = __shfl_up(x, d); if (l >= d) x += y; }
-    return x;
-}
 
 // Distances are lowered by atomics during the sweep, so pre-checks read them past the
 // (non-coherent) vector L1.
@@ -483,19 +485,17 @@ __device__ __forceinline__ i64 ld_dist(const DevGraph &g, int u) {
 
 // Commit up to NJ tentative distances per lane (nd[j] == kDistInf: none) and queue the
 // vertices this wave is the first to improve in this iteration.  Every memory round trip
-// (hub lookup, atomic min, stamp exchange, class lookup) is issued for all NJ candidates
-// before any result is used, so a lane pays each latency once per step, not once per arc.
-// Hubs are only lowered in LDS here; the workgroup commits them once at the end.
+// (atomic min, stamp exchange, class + row lookup) is issued for all NJ candidates before
+// any result is used, so a lane pays each latency once per step, not once per arc.
+// Hubs (hub[j] >= 0) are only lowered in LDS here; the workgroup commits them at the end.
 template <int NJ>
-__device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, unsigned *dcnt, int *dlow, int2 *dseg, i64 *hub_min,
-                                                const int (&hd)[NJ], i64 (&nd)[NJ], unsigned stamp, i64 &wmax, Tally &t) {
+__device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, unsigned *dcnt, int2 *dlow, int4 *dseg, i64 *hub_min,
+                                                const int (&hd)[NJ], const int (&hub)[NJ], const i64 (&nd)[NJ], unsigned stamp,
+                                                unsigned rot, i64 &wmax, Tally &t) {
     bool anyc = false;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) anyc |= nd[j] < kDistInf;
     if (!__ballot(anyc)) return;
-    int hub[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) hub[j] = nd[j] < kDistInf ? g.hub_of[hd[j]] : -1;
     i64 old[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -516,49 +516,52 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
         }
     }
     int cls[NJ];
-    unsigned nl = 0, ns = 0;
+    unsigned r0[NJ], r1[NJ], nl = 0, ns = 0;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) cls[j] = st[j] != stamp ? (int)g.cls[hd[j]] : -1;  // first improver queues it
+    for (int j = 0; j < NJ; ++j) {  // first improver in this iteration queues the vertex
+        const bool enq = st[j] != stamp;
+        cls[j] = enq ? (int)g.cls[hd[j]] : -1;
+        r0[j] = enq ? g.row[hd[j]] : 0;
+        r1[j] = enq ? g.row[hd[j] + 1] : 0;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { nl += cls[j] == kClsLow; ns += cls[j] == kClsMed; }
-    if (!__ballot((nl | ns) != 0)) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) if (cls[j] == kClsHigh) {
-            const unsigned nseg = nseg_of(g, hd[j]);
-            const unsigned base = aadd32(&dcnt[kClsSeg], nseg);
-            for (unsigned s = 0; s < nseg; ++s) dseg[base + s] = make_int2(hd[j], (int)s);
-        }
-        return;
-    }
-    // lane-list entries
-    {
+    if (__ballot(nl != 0)) {
         const unsigned incl = wave_incl_scan_u32(nl);
         const unsigned tot = __shfl(incl, 63);
-        if (tot) {
-            if (q.nlow + tot > kQCap) waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
+        if (q.nlow + tot > kQCap) waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
+        if (tot > kQCap) {  // more than the staging queue holds: straight to memory
+            unsigned base = 0;
+            if (lane_id() == 0) base = aadd32(&dcnt[kClsLow], tot);
+            unsigned pos = __shfl(base, 0) + incl - nl;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsLow) dlow[pos++] = low_item(hd[j], r0[j], r1[j]);
+        } else {
             unsigned pos = q.nlow + incl - nl;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsLow) q.low[pos++] = hd[j];
+            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsLow) q.low[pos++] = low_item(hd[j], r0[j], r1[j]);
             q.nlow += tot;
         }
     }
-    {
+    if (__ballot(ns != 0)) {
         const unsigned incl = wave_incl_scan_u32(ns);
         const unsigned tot = __shfl(incl, 63);
-        if (tot) {
-            if (q.nseg + tot > kQCap) waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);
+        if (q.nseg + tot > kQCap) waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);
+        if (tot > kQCap) {
+            unsigned base = 0;
+            if (lane_id() == 0) base = aadd32(&dcnt[kClsSeg], tot);
+            unsigned pos = __shfl(base, 0) + incl - ns;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsMed) dseg[pos++] = solo_item(hd[j], r0[j], r1[j]);
+        } else {
             unsigned pos = q.nseg + incl - ns;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsMed) q.seg[pos++] = make_int2(hd[j], 0);
+            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsMed) q.seg[pos++] = solo_item(hd[j], r0[j], r1[j]);
             q.nseg += tot;
         }
     }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) if (cls[j] == kClsHigh) {
-        const unsigned nseg = nseg_of(g, hd[j]);
-        const unsigned base = aadd32(&dcnt[kClsSeg], nseg);
-        for (unsigned s = 0; s < nseg; ++s) dseg[base + s] = make_int2(hd[j], (int)s);
-    }
+    for (int j = 0; j < NJ; ++j) if (cls[j] == kClsHigh) append_split(dcnt, dseg, hd[j], r0[j], r1[j], rot ^ (unsigned)hd[j]);
 }
 
 __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
@@ -573,8 +576,8 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
         const unsigned i = aadd32(g.dbg_cnt, 1u);
         if (i < kDbgCap) g.dbg[i] = make_int4(2, k, (int)nlow, (int)nseg);
     }
-    __shared__ int lds_low[(kBlock / 64) * kQCap];
-    __shared__ int2 lds_seg[(kBlock / 64) * kQCap];
+    __shared__ int2 lds_low[(kBlock / 64) * kQCap];
+    __shared__ int4 lds_seg[(kBlock / 64) * kQCap];
     __shared__ i64 s_hmin[kMaxHubs];
     for (int i = threadIdx.x; i < kMaxHubs; i += kBlock) s_hmin[i] = kDistInf;
     __syncthreads();
@@ -583,51 +586,57 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
     q.seg = lds_seg + (threadIdx.x >> 6) * kQCap;
     q.nlow = q.nseg = 0;
     unsigned *dcnt = ct->fr_cnt[dst];
-    int *dlow = g.fr_low[dst];
-    int2 *dseg = g.fr_seg[dst];
+    int2 *dlow = g.fr_low[dst];
+    int4 *dseg = g.fr_seg[dst];
     const i64 S = g.scale;
     const int sh = ct->eps_shift;
     const unsigned stamp = ct->gu_stamp_base + (unsigned)k + 1u;
+    const unsigned rot = mix32(ct->epoch, stamp);
     const int lane = lane_id();
     const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
     i64 wmax = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyGuIters]++;
-    const int2 *segl = g.fr_seg[src];
+    const int4 *segl = g.fr_seg[src];
     for (unsigned i = wave; i < nseg; i += nwaves) {
-        const int2 it = segl[i];
+        const int4 it = segl[i];
         const int v = it.x;
-        const unsigned r0 = g.row[v] + (unsigned)it.y * kWSeg;
-        const unsigned r1 = min(g.row[v + 1], r0 + kWSeg);
+        const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
+        const bool solo = it.w & 1;
         const i64 dv = g.dist[v], pv = g.price[v];
-        for (unsigned h = r0; h < r1; h += 512) {
-            const unsigned a0 = h + lane * 8;
-            int rc8[8];
-            load8(g.rcap, a0, r1, rc8);
-            if (a0 < r1) t.c[kTallyGuScans] += min(8u, r1 - a0);
-            bool anyc = false;
+        for (unsigned h = r0; h < r1; h += kStep) {
+            const unsigned a0 = h + lane * 8, lim8 = min(r1, h + 512), at = h + 512 + lane, limt = min(r1, h + kStep);
+            int rc9[9], hd[9], cs[9];
+            load9(g.rcap, a0, lim8, at, limt, rc9);
+            t.c[kTallyGuScans] += count9(a0, lim8, at, limt);
+            if (solo) {  // small dense rows: fetch everything in one round trip
+                load9(g.head, a0, lim8, at, limt, hd);
+                load9(g.cost, a0, lim8, at, limt, cs);
+            } else {     // hub rows: most arcs fail the capacity test, stream 4 B per arc
+                bool anyc = false;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) anyc |= rc8[j] > 0;
-            if (!__ballot(anyc)) continue;
-            int hd[8], cs[8];
-            if (anyc) { load8(g.head, a0, r1, hd); load8(g.cost, a0, r1, cs); }
-            else {
+                for (int j = 0; j < 9; ++j) anyc |= rc9[j] > 0;
+                if (!__ballot(anyc)) continue;
+                if (anyc) { load9(g.head, a0, lim8, at, limt, hd); load9(g.cost, a0, lim8, at, limt, cs); }
+                else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { hd[j] = 0; cs[j] = 0; }
+                    for (int j = 0; j < 9; ++j) { hd[j] = 0; cs[j] = 0; }
+                }
             }
-            // tentative distances; consecutive arcs to the same vertex are merged
-            i64 pu[8], du[8], nd[8];
+            i64 pu[9], du[9], nd[9];
+            int hub[9];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool ok = rc8[j] > 0;
+            for (int j = 0; j < 9; ++j) {
+                const bool ok = rc9[j] > 0;
                 pu[j] = ok ? g.price[hd[j]] : 0;
                 du[j] = ok ? ld_dist(g, hd[j]) : 0;
+                hub[j] = ok ? g.hub_of[hd[j]] : -1;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 9; ++j) {
                 nd[j] = kDistInf;
-                if (rc8[j] > 0) {
+                if (rc9[j] > 0) {
                     const i64 rc = -(i64)cs[j] * S + pu[j] - pv;
                     i64 l = (rc >> sh) + 1;
                     if (l < 0) l = 0;
@@ -635,31 +644,36 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
                 }
             }
 #pragma unroll
-            for (int j = 1; j < 8; ++j) {
+            for (int j = 1; j < 8; ++j) {  // consecutive arcs to the same vertex: keep one candidate
                 if (nd[j] < kDistInf && nd[j - 1] < kDistInf && hd[j] == hd[j - 1]) {
                     nd[j] = nd[j] < nd[j - 1] ? nd[j] : nd[j - 1];
                     nd[j - 1] = kDistInf;
                 }
             }
-            gu_commit_batch<8>(g, q, dcnt, dlow, dseg, s_hmin, hd, nd, stamp, wmax, t);
+            gu_commit_batch<9>(g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
         }
     }
-    const int *lowl = g.fr_low[src];
+    const int2 *lowl = g.fr_low[src];
     const unsigned nlow_round = (nlow + 63) & ~63u;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow_round; i += gridDim.x * kBlock) {
         const bool have = i < nlow;
-        const int v = have ? lowl[i] : 0;
-        const unsigned r0 = have ? g.row[v] : 0, r1 = have ? g.row[v + 1] : 0;
+        const int2 it = have ? lowl[i] : make_int2(0, 0);
+        const int v = it.x & 0x0FFFFFFF;
+        const unsigned deg = have ? (unsigned)it.x >> 28 : 0u, r0 = (unsigned)it.y;
         const i64 dv = have ? g.dist[v] : 0, pv = have ? g.price[v] : 0;
-        int rc4[kLowMax], hd[kLowMax], cs[kLowMax];
+        int rc4[kLowMax], hd[kLowMax], cs[kLowMax], hub[kLowMax];
         i64 pu[kLowMax], du[kLowMax], nd[kLowMax];
 #pragma unroll
-        for (unsigned j = 0; j < kLowMax; ++j) rc4[j] = r0 + j < r1 ? g.rcap[r0 + j] : 0;
-        t.c[kTallyGuScans] += r1 - r0;
+        for (unsigned j = 0; j < kLowMax; ++j) {
+            const bool ok = j < deg;
+            rc4[j] = ok ? g.rcap[r0 + j] : 0; hd[j] = ok ? g.head[r0 + j] : 0; cs[j] = ok ? g.cost[r0 + j] : 0;
+        }
+        t.c[kTallyGuScans] += deg;
 #pragma unroll
-        for (unsigned j = 0; j < kLowMax; ++j) { hd[j] = rc4[j] > 0 ? g.head[r0 + j] : 0; cs[j] = rc4[j] > 0 ? g.cost[r0 + j] : 0; }
-#pragma unroll
-        for (unsigned j = 0; j < kLowMax; ++j) { pu[j] = rc4[j] > 0 ? g.price[hd[j]] : 0; du[j] = rc4[j] > 0 ? ld_dist(g, hd[j]) : 0; }
+        for (unsigned j = 0; j < kLowMax; ++j) {
+            const bool ok = rc4[j] > 0;
+            pu[j] = ok ? g.price[hd[j]] : 0; du[j] = ok ? ld_dist(g, hd[j]) : 0; hub[j] = ok ? g.hub_of[hd[j]] : -1;
+        }
 #pragma unroll
         for (unsigned j = 0; j < kLowMax; ++j) {
             nd[j] = kDistInf;
@@ -670,32 +684,22 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
                 if (dv + l < du[j]) nd[j] = dv + l;
             }
         }
-        gu_commit_batch<(int)kLowMax>(g, q, dcnt, dlow, dseg, s_hmin, hd, nd, stamp, wmax, t);
+        gu_commit_batch<(int)kLowMax>(g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
     }
     __syncthreads();  // hub minima of the whole workgroup are in LDS
     for (int base = 0; base < g.nhubs; base += kBlock) {
         const int i = base + (int)threadIdx.x;
-        int hd[1] = {0};
-        i64 nd[1] = {kDistInf};
         if (i < g.nhubs && s_hmin[i] < kDistInf) {
-            hd[0] = g.hub_vertex[i];
-            if (s_hmin[i] < ld_dist(g, hd[0])) nd[0] = s_hmin[i];
-        }
-        bool anyc = nd[0] < kDistInf;
-        if (__ballot(anyc)) {
-            bool enq = false;
-            if (anyc) {
-                const i64 old = amin64(&g.dist[hd[0]], nd[0]);
-                if (nd[0] < old) {
+            const int u = g.hub_vertex[i];
+            const i64 nd = s_hmin[i];
+            if (nd < ld_dist(g, u)) {
+                const i64 old = amin64(&g.dist[u], nd);
+                if (nd < old) {
                     t.c[kTallyGuRelax]++;
-                    if (nd[0] > wmax) wmax = nd[0];
-                    enq = axchg32(&g.fstamp[hd[0]], stamp) != stamp;
+                    if (nd > wmax) wmax = nd;
+                    if (axchg32(&g.fstamp[u], stamp) != stamp)  // hubs are always split vertices
+                        append_split(dcnt, dseg, u, g.row[u], g.row[u + 1], rot ^ (unsigned)u);
                 }
-            }
-            if (enq) {  // hubs are always multi-item vertices
-                const unsigned ns = nseg_of(g, hd[0]);
-                const unsigned b = aadd32(&dcnt[kClsSeg], ns);
-                for (unsigned s2 = 0; s2 < ns; ++s2) dseg[b + s2] = make_int2(hd[0], (int)s2);
             }
         }
     }
@@ -711,16 +715,23 @@ __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_init_on) return;
     __shared__ unsigned s_app[2][kBlock / 64 + 1];
-    const int nround = (g.n + kBlock - 1) / kBlock * kBlock;
-    for (int v = blockIdx.x * kBlock + threadIdx.x; v < nround; v += gridDim.x * kBlock) {
-        bool def = false;
-        int cls = 0;
-        if (v < g.n) {
-            def = g.excess[v] < 0;
-            g.dist[v] = def ? 0 : kDistInf;
-            cls = g.cls[v];
+    const unsigned rot = mix32(ct->epoch, 0x5EEDu);
+    const int span = kBlock * kVpt;
+    for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
+        bool def[kVpt];
+        int v[kVpt], cls[kVpt];
+        unsigned r0[kVpt], r1[kVpt];
+#pragma unroll
+        for (int i = 0; i < kVpt; ++i) {
+            v[i] = base + i * kBlock + (int)threadIdx.x;
+            const bool in = v[i] < g.n;
+            def[i] = in && g.excess[v[i]] < 0;
+            cls[i] = in ? (int)g.cls[v[i]] : 0;
+            if (in) g.dist[v[i]] = def[i] ? 0 : kDistInf;
         }
-        block_append(g, ct->fr_cnt[0], g.fr_low[0], g.fr_seg[0], def, v, cls, s_app);
+#pragma unroll
+        for (int i = 0; i < kVpt; ++i) { r0[i] = def[i] ? g.row[v[i]] : 0; r1[i] = def[i] ? g.row[v[i] + 1] : 0; }
+        block_append<kVpt>(ct->fr_cnt[0], g.fr_low[0], g.fr_seg[0], def, v, cls, r0, r1, rot, s_app);
     }
 }
 

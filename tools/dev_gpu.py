@@ -46,5 +46,5 @@ if __name__ == "__main__":
     cfg = int(args[0]) if args else 0
     seed = int(args[1]) if len(args) > 1 else 1
     eager = len(args) > 2 and args[2] == "eager"
-    run(cfg, seed, eager=eager, repeat=int(os.environ.get("REPEAT", "1")), rounds=int(os.environ.get("ROUNDS", "0")),
+    run(cfg, seed, eager=eager, check="nocheck" not in args, repeat=int(os.environ.get("REPEAT", "1")), rounds=int(os.environ.get("ROUNDS", "0")),
         alpha=int(os.environ.get("ALPHA", "0")))
