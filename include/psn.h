@@ -43,11 +43,12 @@ typedef struct psn_ctx psn_ctx;
 
 typedef struct psn_config {
     int32_t device;          /* HIP device ordinal */
-    int32_t alpha_log2;      /* epsilon divisor per refine = 2^alpha_log2 (0 -> default 3) */
+    int32_t alpha_log2;      /* epsilon divisor per refine = 2^alpha_log2 (0 -> default 4) */
     int32_t rounds_per_batch;/* push/relabel rounds between global price updates (0 -> default) */
     int32_t flags;           /* PSN_CFG_* */
 } psn_config;
 #define PSN_CFG_EAGER 1      /* plain launches instead of hipGraph replay (debugging) */
+#define PSN_CFG_EPS_FROM_MAX 4 /* first epsilon from the largest |cost| (textbook) instead of the 90th-percentile cost */
 #define PSN_CFG_KTIME 2      /* with PSN_CFG_EAGER: HIP-event time every sweep launch (psn_kernel_times) */
 
 /* kernel classes reported by psn_kernel_times */

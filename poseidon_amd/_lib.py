@@ -18,6 +18,7 @@ PSN_EOVERFLOW, PSN_ESTATE, PSN_ELIMIT = -5, -6, -7
 PSN_WARM_START = 1
 PSN_CFG_EAGER = 1
 PSN_CFG_KTIME = 2
+PSN_CFG_EPS_FROM_MAX = 4
 KT_NAMES = ["push", "gu_expand", "relabel_compact", "saturate", "other"]
 
 EXPORTS = [

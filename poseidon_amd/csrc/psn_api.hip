@@ -33,7 +33,7 @@ struct psn_ctx {
     std::vector<void *> bufs;
     i64 *d_supply = nullptr;
     int *d_cost = nullptr, *d_ocap = nullptr;  // non-const aliases of g.cost / g.ocap
-    i64 *d_scalar = nullptr;                   // [0] total cost, [1] max |cost|, [2] max violation
+    i64 *d_scalar = nullptr;                   // [0] total cost, [1] max violation, [2..] k_cost_stats output
     unsigned long long *d_tally_out = nullptr;
     int tally_slots = 0;
     // placements scratch
@@ -140,13 +140,29 @@ int build_graph(psn_ctx *c) {
     return PSN_OK;
 }
 
-__global__ void k_max_abs_cost(DevGraph g, i64 *out) {
+// Cost statistics of the arcs that can carry flow: out[0] = max |cost|, out[1] = number with a
+// negative cost, out[2 + b] = number with 2^(b-1) < cost <= 2^b (b = 0 holds costs 0 and 1).
+__global__ void k_cost_stats(DevGraph g, i64 *out) {
+    __shared__ unsigned s_hist[33];
+    if (threadIdx.x < 33) s_hist[threadIdx.x] = 0;
+    __syncthreads();
     i64 mx = 0;
     for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) {
-        if (g.ocap[a] > 0 || g.ocap[g.rev[a]] > 0) { i64 c = g.cost[a]; c = c < 0 ? -c : c; mx = c > mx ? c : mx; }
+        const bool fwd = g.ocap[a] > 0;
+        if (fwd || g.ocap[g.rev[a]] > 0) { i64 c = g.cost[a]; c = c < 0 ? -c : c; mx = c > mx ? c : mx; }
+        if (fwd) {
+            const int c = g.cost[a];
+            const int b = c < 0 ? 32 : (c <= 1 ? 0 : 32 - __clz(c - 1));
+            atomicAdd(&s_hist[b], 1u);
+        }
     }
     for (int d = 32; d; d >>= 1) { i64 y = __shfl_xor(mx, d); mx = y > mx ? y : mx; }
     if ((threadIdx.x & 63) == 0 && mx > 0) __hip_atomic_fetch_max(out, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x < 33 && s_hist[threadIdx.x]) {
+        i64 *dst = threadIdx.x == 32 ? out + 1 : out + 2 + threadIdx.x;
+        __hip_atomic_fetch_add(dst, (i64)s_hist[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 // Largest amount by which a residual arc's reduced cost is below zero (warm start).
 __global__ void k_max_violation(DevGraph g, i64 *out) {
@@ -160,6 +176,8 @@ __global__ void k_max_violation(DevGraph g, i64 *out) {
     for (int d = 32; d; d >>= 1) { i64 y = __shfl_xor(mx, d); mx = y > mx ? y : mx; }
     if ((threadIdx.x & 63) == 0 && mx > 0) __hip_atomic_fetch_max(out, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+constexpr int kScalarSlots = 40;
 
 int ceil_log2(i64 x) {
     int s = 0;
@@ -197,8 +215,8 @@ int psn_create(const psn_config *cfg, psn_ctx **out) {
     psn_ctx *c = new (std::nothrow) psn_ctx();
     if (!c) return PSN_ENOMEM;
     if (cfg) c->cfg = *cfg;
-    if (c->cfg.alpha_log2 <= 0 || c->cfg.alpha_log2 > 8) c->cfg.alpha_log2 = 3;
-    c->rounds = c->cfg.rounds_per_batch > 0 ? c->cfg.rounds_per_batch : 8;
+    if (c->cfg.alpha_log2 <= 0 || c->cfg.alpha_log2 > 8) c->cfg.alpha_log2 = 4;
+    c->rounds = c->cfg.rounds_per_batch > 0 ? c->cfg.rounds_per_batch : 12;
     if (c->rounds & 1) ++c->rounds;  // list parity must be the same at every replay start
     if (c->rounds > 62) c->rounds = 62;
     c->device = c->cfg.device;
@@ -299,7 +317,7 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
 #define A(p, cnt) if ((rc = dalloc(c, &(p), (size_t)(cnt))) != PSN_OK) { free_graph_buffers(c); return rc; }
     A(d_row, n + 1) A(d_head, m2) A(c->d_cost, m2) A(d_rev, m2) A(d_tail, m2) A(c->d_ocap, m2) A(d_cls, n) A(d_hub_of, n) A(d_hub_vertex, kMaxHubs)
     A(g.cap, m2) A(g.rcap, m2) A(g.price, n) A(g.excess, n) A(g.cand, n) A(g.dist, n) A(g.fstamp, n)
-    A(c->d_supply, n) A(c->d_scalar, 8)
+    A(c->d_supply, n) A(c->d_scalar, kScalarSlots)
     for (int i = 0; i < 2; ++i) { A(g.list_low[i], n) A(g.list_seg[i], (size_t)n + high_items) }
     for (int i = 0; i < 3; ++i) { A(g.fr_low[i], n) A(g.fr_seg[i], (size_t)n + high_items) }
     c->tally_slots = kGrid * (kBlock / 64);
@@ -436,23 +454,36 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     hipLaunchKernelGGL(k_reset, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_supply, warm ? 1 : 0);
     hipLaunchKernelGGL(k_mirror, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_supply, warm ? 1 : 0);
     if (warm) hipLaunchKernelGGL(k_excess_from_flow, dim3(kGrid), dim3(kBlock), 0, s, g);
-    HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 8 * sizeof(i64), s));
+    HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, kScalarSlots * sizeof(i64), s));
     HIPCHK(c, hipMemsetAsync(g.tally, 0, (size_t)c->tally_slots * kTallyN * sizeof(unsigned long long), s));
     if (g.dbg_cnt) HIPCHK(c, hipMemsetAsync(g.dbg_cnt, 0, sizeof(unsigned), s));
-    hipLaunchKernelGGL(k_max_abs_cost, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 1);
-    if (warm) hipLaunchKernelGGL(k_max_violation, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 2);
-    i64 h_scalar[3] = {0, 0, 0};
+    if (!warm) hipLaunchKernelGGL(k_cost_stats, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 2);
+    if (warm) hipLaunchKernelGGL(k_max_violation, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 1);
+    i64 h_scalar[kScalarSlots] = {};
     HIPCHK(c, hipMemcpyAsync(h_scalar, c->d_scalar, sizeof(h_scalar), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     Ctrl init{};
     init.alpha_log2 = c->cfg.alpha_log2;
     int shift0;
     if (!warm) {
-        const i64 maxc = std::max<i64>(1, h_scalar[1]) * g.scale;
-        shift0 = ceil_log2(maxc) - init.alpha_log2;
+        // Zero flow with zero prices is 0-optimal when no usable arc has a negative cost, so the
+        // first phase may start anywhere; starting at the 90th-percentile cost bucket instead of
+        // the largest cost skips the phases in which only a few expensive arcs (the unscheduled
+        // penalty) are distinguishable.  Any starting epsilon is correct: every phase first
+        // saturates the arcs that violate its epsilon.
+        i64 c0 = std::max<i64>(1, h_scalar[2]);
+        if (h_scalar[3] == 0 && !(c->cfg.flags & PSN_CFG_EPS_FROM_MAX)) {
+            i64 total = 0, run = 0;
+            for (int b = 0; b < 32; ++b) total += h_scalar[4 + b];
+            for (int b = 0; b < 32; ++b) {
+                run += h_scalar[4 + b];
+                if (run * 10 >= total * 9) { c0 = std::min<i64>(c0, (i64)1 << b); break; }
+            }
+        }
+        shift0 = ceil_log2(c0 * g.scale) - init.alpha_log2;
     } else {
         // the kept pseudoflow is v-optimal for v = largest violation: resume one step below it
-        shift0 = h_scalar[2] > 1 ? ceil_log2(h_scalar[2]) - init.alpha_log2 : 0;
+        shift0 = h_scalar[1] > 1 ? ceil_log2(h_scalar[1]) - init.alpha_log2 : 0;
     }
     if (shift0 < 0) shift0 = 0;
     init.eps_shift = shift0;

@@ -17,7 +17,7 @@ constexpr unsigned kStep = 576;  // arcs per wave step: 8 consecutive per lane +
 constexpr unsigned kWSeg = 2 * kStep;  // arcs per wave work item; larger vertices are split into several items
 constexpr unsigned kMedMax = kWSeg;  // degree <= kMedMax: the whole vertex is one wave item
 constexpr unsigned kQCap = 256;  // entries per per-wave LDS frontier staging queue
-constexpr int kVpt = 4;          // vertices per thread in the vertex sweeps
+constexpr int kVpt = 2;          // vertices per thread in the vertex sweeps
 constexpr int kMaxVertices = 1 << 28;  // lane items pack the degree above bit 28
 constexpr int kClsLow = 0, kClsMed = 1, kClsHigh = 2;  // vertex classes by degree
 constexpr int kClsSeg = 1;       // counter slot of the (vertex, segment) item lists (slot 0: lane list)

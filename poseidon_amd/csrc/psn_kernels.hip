@@ -372,19 +372,20 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
         unsigned r0[kVpt], r1[kVpt];
         i64 e[kVpt], c[kVpt], p[kVpt];
 #pragma unroll
-        for (int i = 0; i < kVpt; ++i) {
+        for (int i = 0; i < kVpt; ++i) {  // everything in one round trip: the sweep is latency-bound
             v[i] = base + i * kBlock + (int)threadIdx.x;
             const bool in = v[i] < g.n;
             e[i] = in ? g.excess[v[i]] : 0;
             c[i] = in ? g.cand[v[i]] : kInf;
             cls[i] = in ? (int)g.cls[v[i]] : 0;
+            p[i] = in ? g.price[v[i]] : 0;
+            r0[i] = in ? g.row[v[i]] : 0;
+            r1[i] = in ? g.row[v[i] + 1] : 0;
         }
 #pragma unroll
         for (int i = 0; i < kVpt; ++i) {
             act[i] = e[i] > 0;
-            p[i] = (act[i] && do_relabel && c[i] != kInf && c[i] != kNegInf) ? g.price[v[i]] : kNegInf;
-            r0[i] = act[i] ? g.row[v[i]] : 0;
-            r1[i] = act[i] ? g.row[v[i] + 1] : 0;
+            if (!(act[i] && do_relabel && c[i] != kInf && c[i] != kNegInf)) p[i] = kNegInf;
         }
 #pragma unroll
         for (int i = 0; i < kVpt; ++i) {

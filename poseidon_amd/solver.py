@@ -38,10 +38,11 @@ class SolveResult:
 
 class Solver:
     def __init__(self, device: int = 0, alpha_log2: int = 0, rounds_per_batch: int = 0,
-                 eager: bool = False, time_kernels: bool = False):
+                 eager: bool = False, time_kernels: bool = False, eps_from_max: bool = False):
         self._lib = _lib.load_library()
         self._ctx = C.c_void_p(None)
-        flags = (_lib.PSN_CFG_EAGER if eager or time_kernels else 0) | (_lib.PSN_CFG_KTIME if time_kernels else 0)
+        flags = (_lib.PSN_CFG_EAGER if eager or time_kernels else 0) | (_lib.PSN_CFG_KTIME if time_kernels else 0) \
+            | (_lib.PSN_CFG_EPS_FROM_MAX if eps_from_max else 0)
         cfg = _lib.Config(device, alpha_log2, rounds_per_batch, flags)
         rc = self._lib.psn_create(C.byref(cfg), C.byref(self._ctx))
         if rc != _lib.PSN_OK:

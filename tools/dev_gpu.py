@@ -13,7 +13,7 @@ from oracle import capi, synth
 def run(cfg, seed, eager=False, rounds=0, alpha=0, check=True, nm=None, np_=None, repeat=1):
     cl = pa.synth_cluster(cfg, seed, nm, np_)
     net = pa.build_network(cl)
-    with pa.Solver(eager=eager, rounds_per_batch=rounds, alpha_log2=alpha) as s:
+    with pa.Solver(eager=eager, rounds_per_batch=rounds, alpha_log2=alpha, eps_from_max=bool(int(os.environ.get('EPSMAX', '0')))) as s:
         t = time.time(); s.upload(net); t_up = time.time() - t
         t = time.time(); s.eval_costs(cl, net); t_k1 = time.time() - t
         for _ in range(repeat):

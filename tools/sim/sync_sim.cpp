@@ -37,6 +37,7 @@ struct Sim {
     std::vector<i64> price, excess, delta, cand, dist;
     std::vector<i32> cap;
     int alpha = 8, gu_period = 8, sat_mode = 1;
+    i64 eps0_cap = 0;  // if > 0: first epsilon is min(max scaled cost, eps0_cap * S)
     // stats
     i64 rounds = 0, scans = 0, pushes = 0, relabels = 0, gu_iters = 0, gu_scans = 0, gus = 0, sat_scans = 0;
     Sim(Graph &g_) : g(g_), S(g_.n + 1), price(g_.n, 0), excess(g_.supply), delta(g_.n, 0), cand(g_.n), dist(g_.n), cap(g_.cap) {}
@@ -137,6 +138,7 @@ struct Sim {
         i64 eps = 1;
         for (i64 a = 0; a < g.m2; ++a) if (cap[a] > 0) eps = std::max<i64>(eps, std::abs((i64)g.cost[a]) * S);
         std::fill(cand.begin(), cand.end(), INT64_MIN);
+        if (eps0_cap > 0) eps = std::min<i64>(eps, eps0_cap * S);
         do { eps = std::max<i64>(1, eps / alpha); refine(eps); } while (eps > 1);
         i64 tc = 0;
         for (i64 a = 0; a < g.m2; ++a) { i64 f = (i64)g.cap[a] - cap[a]; if (f > 0) tc += f * g.cost[a]; }
@@ -151,6 +153,7 @@ int main(int argc, char **argv) {
     if (argc > 2) s.alpha = atoi(argv[2]);
     if (argc > 3) s.gu_period = atoi(argv[3]);
     if (argc > 4) s.sat_mode = atoi(argv[4]);
+    if (argc > 5) s.eps0_cap = atoll(argv[5]);
     auto t0 = std::chrono::steady_clock::now();
     i64 tc = s.solve();
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
