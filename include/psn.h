@@ -125,6 +125,32 @@ int psn_eval_costs(psn_ctx *ctx, const psn_layout *layout, const int64_t *cap_cp
 int psn_update_caps(psn_ctx *ctx, int64_t count, const int64_t *arc_index, const int32_t *new_cap);
 int psn_update_supplies(psn_ctx *ctx, int64_t count, const int32_t *vertex, const int64_t *new_supply);
 
+/* Same pricing as psn_eval_costs, for a network that keeps its state between rounds: the
+ * flow on every slot arc is kept (cut down to the new capacity), prices and the solved
+ * state stay, so the next psn_solve(PSN_WARM_START) repairs instead of starting over.
+ * This is the path of a machine whose usage or capacity changed (NodeUpdated,
+ * /root/reference/pkg/firmament/firmament_scheduler.proto:37; AddNodeStats, :41). */
+int psn_reprice_costs(psn_ctx *ctx, const psn_layout *layout, const int64_t *cap_cpu,
+                      const int64_t *cap_mem, const int64_t *used_cpu, const int64_t *used_mem,
+                      const int64_t *req_cpu, const int64_t *req_mem, const int64_t *ec_arc_base);
+
+/* Rewire residual arcs in place: entry i overwrites arc arc_index[i] with (head, original
+ * capacity, cost, index of its paired arc); the tail of an arc is fixed by its row.  Flow
+ * on a patched arc is dropped, so both arcs of a pair must be patched together; an unused
+ * slot is parked as a placeholder paired with itself (head = its own tail, capacity 0,
+ * cost 0).  The device checks that every patched arc pairs up again; if not, PSN_EINVAL is
+ * returned and the network has to be uploaded again.  This is how a task that arrives,
+ * leaves or changes class (TaskSubmitted / TaskRemoved,
+ * /root/reference/pkg/firmament/firmament_scheduler.proto:24,26) changes the resident
+ * network without a new upload. */
+int psn_patch_arcs(psn_ctx *ctx, int64_t count, const int64_t *arc_index, const int32_t *head,
+                   const int32_t *cap, const int32_t *cost, const int32_t *rev);
+
+/* Give vertices that no residual arc enters (new tasks) the lowest price that leaves none
+ * of their own arcs violated, so that a warm start does not restart from a large epsilon
+ * because of them.  Vertices that are entered are left alone and counted in *skipped. */
+int psn_settle_sources(psn_ctx *ctx, int64_t count, const int32_t *vertex, int64_t *skipped);
+
 /* The scheduling solve itself: cost-scaling push-relabel on the device.  Replaces
  * the solver run inside Firmament's Schedule handler
  * (/root/reference/pkg/firmament/firmament_scheduler.proto:17). */

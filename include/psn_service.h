@@ -1,0 +1,148 @@
+/*
+ * libpsn scheduler service core: the state machine behind the Firmament scheduler RPCs,
+ * host-side C ABI above the solver (include/psn.h).
+ *
+ * One psn_svc is what a Go type implementing FirmamentSchedulerServer
+ * (/root/reference/pkg/firmament/firmament_scheduler.pb.go:600-614) holds: every RPC of
+ * the service (/root/reference/pkg/firmament/firmament_scheduler.proto:15-45) maps to one
+ * call below, with the protobuf payload reduced to the fields the reference actually fills
+ * in (/root/reference/pkg/k8sclient/podwatcher.go:377-410,
+ * /root/reference/pkg/k8sclient/nodewatcher.go:292-339).  The calls return the reply enum
+ * of the RPC (values of TaskReplyType / NodeReplyType,
+ * /root/reference/pkg/firmament/firmament_scheduler.proto:110-129) or a negative PSN_E*
+ * code; the unmodified client accepts exactly those replies
+ * (/root/reference/pkg/firmament/firmament_client.go:43-179).
+ *
+ * The service keeps the flow network resident on the GPU between rounds.  Tasks, jobs,
+ * classes and machines own fixed places in a network that is laid out with head-room;
+ * an RPC edits the host mirror and queues the few arcs, capacities and supplies it
+ * touched; Schedule ships those to the device and repairs the previous solution
+ * (warm start).  Only when head-room runs out is the network laid out and uploaded again.
+ *
+ * Not thread-safe: the caller serialises calls (one mutex around the service, as
+ * Firmament's own scheduling lock does).
+ */
+#ifndef PSN_SERVICE_H_
+#define PSN_SERVICE_H_
+
+#include <stdint.h>
+#include "psn.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* TaskReplyType, /root/reference/pkg/firmament/firmament_scheduler.proto:110-120 */
+#define PSN_TASK_COMPLETED_OK 0
+#define PSN_TASK_SUBMITTED_OK 1
+#define PSN_TASK_REMOVED_OK 2
+#define PSN_TASK_FAILED_OK 3
+#define PSN_TASK_UPDATED_OK 4
+#define PSN_TASK_NOT_FOUND 5
+#define PSN_TASK_JOB_NOT_FOUND 6
+#define PSN_TASK_ALREADY_SUBMITTED 7
+#define PSN_TASK_STATE_NOT_CREATED 8
+/* NodeReplyType, :122-129 */
+#define PSN_NODE_ADDED_OK 0
+#define PSN_NODE_FAILED_OK 1
+#define PSN_NODE_REMOVED_OK 2
+#define PSN_NODE_UPDATED_OK 3
+#define PSN_NODE_NOT_FOUND 4
+#define PSN_NODE_ALREADY_EXISTS 5
+/* ServingStatus, :131-135 */
+#define PSN_SERVING_UNKNOWN 0
+#define PSN_SERVING 1
+#define PSN_NOT_SERVING 2
+/* SchedulingDelta.ChangeType, /root/reference/pkg/firmament/scheduling_delta.proto:26-35 */
+#define PSN_DELTA_NOOP 0
+#define PSN_DELTA_PLACE 1
+#define PSN_DELTA_PREEMPT 2
+#define PSN_DELTA_MIGRATE 3
+/* TaskDescriptor.TaskState CREATED, /root/reference/pkg/firmament/task_desc.proto:32-33 */
+#define PSN_TASK_STATE_CREATED 0
+
+typedef struct psn_svc psn_svc;
+
+typedef struct psn_svc_config {
+    int32_t device;            /* HIP device ordinal; -1: no device (state machine and network
+                                  export only, psn_svc_schedule fails with PSN_ESTATE) */
+    int32_t max_machines;      /* initial capacities of the resident network; 0: sized from */
+    int32_t max_tasks;         /*   what is known at the first Schedule plus 25 % */
+    int32_t max_jobs;
+    int32_t max_classes;       /* distinct (cpu, memory) request shapes; 0 -> 64 */
+    int32_t k_slots;           /* parallel unit arcs per (class, machine); 0 -> 8 */
+    int32_t slots_per_machine; /* machine -> sink capacity; 0 -> 12 */
+    int32_t unsched_cost;      /* cost of leaving a task unscheduled; 0 -> 2 560 000 */
+    int32_t emit_noop;         /* 1: report unchanged tasks as NOOP deltas too */
+    psn_config solver;         /* passed to psn_create (device field overwritten) */
+} psn_svc_config;
+
+typedef struct psn_svc_stats {
+    int64_t rounds, rebuilds, warm_rounds; /* Schedule calls, full uploads, warm-started solves */
+    int64_t patched_arcs, cap_updates, supply_updates; /* records shipped by the last Schedule */
+    int64_t tasks_runnable, tasks_placed, machines_live;
+    int64_t n, m2;                          /* resident network size */
+    double build_ms, upload_ms, update_ms, solve_ms, extract_ms; /* last Schedule, host clock */
+    int64_t total_cost;
+    int32_t last_round_warm;
+} psn_svc_stats;
+
+int psn_svc_create(const psn_svc_config *cfg, psn_svc **out);
+void psn_svc_destroy(psn_svc *svc);
+const char *psn_svc_last_error(const psn_svc *svc);
+
+/* TaskSubmitted (/root/reference/pkg/firmament/firmament_scheduler.proto:26): task uid
+ * (/root/reference/pkg/k8sclient/podwatcher.go:420-422), job uuid, TaskDescriptor.state,
+ * cpu request in millicores and memory request in Kb (podwatcher.go:382-386). */
+int psn_svc_task_submitted(psn_svc *svc, uint64_t task_uid, const char *job_uuid, int32_t state,
+                           int64_t cpu_millicores, int64_t ram_kb);
+/* TaskUpdated (:28): same payload; the task may change its request shape. */
+int psn_svc_task_updated(psn_svc *svc, uint64_t task_uid, const char *job_uuid, int64_t cpu_millicores,
+                         int64_t ram_kb);
+/* TaskCompleted / TaskFailed / TaskRemoved (:20-24). */
+int psn_svc_task_completed(psn_svc *svc, uint64_t task_uid);
+int psn_svc_task_failed(psn_svc *svc, uint64_t task_uid);
+int psn_svc_task_removed(psn_svc *svc, uint64_t task_uid);
+
+/* NodeAdded / NodeUpdated (:31,37): resource uuid of the machine
+ * (/root/reference/pkg/k8sclient/nodewatcher.go:296-306) and its capacity in millicores / Kb
+ * (nodewatcher.go:300-303).  NodeFailed / NodeRemoved (:33-35). */
+int psn_svc_node_added(psn_svc *svc, const char *resource_uuid, int64_t cpu_millicores, int64_t ram_kb);
+int psn_svc_node_updated(psn_svc *svc, const char *resource_uuid, int64_t cpu_millicores, int64_t ram_kb);
+int psn_svc_node_failed(psn_svc *svc, const char *resource_uuid);
+int psn_svc_node_removed(psn_svc *svc, const char *resource_uuid);
+/* AddNodeStats (:42): resources in use on the machine by anything that is not one of the
+ * tasks known to the service; feeds the cost model.  Reply as for NodeUpdated. */
+int psn_svc_add_node_stats(psn_svc *svc, const char *resource_uuid, int64_t used_cpu_millicores, int64_t used_ram_kb);
+/* AddTaskStats (:40): accepted and ignored (the client ignores the reply,
+ * /root/reference/pkg/firmament/firmament_client.go:183-188). */
+int psn_svc_add_task_stats(psn_svc *svc, uint64_t task_uid);
+/* Check (:44). */
+int psn_svc_check(const psn_svc *svc);
+
+/* Schedule (:17): one scheduling round.  Returns the number of deltas (>= 0) or a negative
+ * PSN_E* code; the deltas stay readable until the next round. */
+int64_t psn_svc_schedule(psn_svc *svc);
+/* Copy deltas [first, first+count): task uid, change type and the 36-character resource
+ * uuid of the machine (NUL-terminated, 37 bytes per delta; empty for PREEMPT). */
+int psn_svc_get_deltas(psn_svc *svc, int64_t first, int64_t count, uint64_t *task_uid, int32_t *type,
+                       char *resource_uuid /* count * 37 */);
+int psn_svc_get_stats(const psn_svc *svc, psn_svc_stats *out);
+
+/* Inspection: the host mirror of the resident network as psn_upload_csr would take it
+ * (slot arcs unpriced: cost 0, capacity 0) plus what psn_eval_costs needs.  Sizes first
+ * (any pointer may be NULL), then the arrays. */
+int psn_svc_network_size(psn_svc *svc, psn_layout *layout, int32_t *n, int64_t *m2);
+int psn_svc_export_network(psn_svc *svc, int64_t *row_off, int32_t *head, int32_t *cap, int32_t *cost,
+                           int32_t *rev, int64_t *supply, int64_t *ec_arc_base, int64_t *cap_cpu,
+                           int64_t *cap_mem, int64_t *used_cpu, int64_t *used_mem, int64_t *req_cpu,
+                           int64_t *req_mem);
+/* Current placement of a task: machine uuid (37 bytes) or empty when unscheduled/unknown. */
+int psn_svc_task_placement(psn_svc *svc, uint64_t task_uid, char *resource_uuid /* 37 */);
+/* The solver context of the service (NULL without a device), for read-backs in tests. */
+psn_ctx *psn_svc_solver(psn_svc *svc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSN_SERVICE_H_ */

@@ -47,6 +47,11 @@ def _p(a, dtype):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _m2(g) -> int:
+    """Residual arc count: 2m, unless the network carries self-paired placeholder arcs."""
+    return int(g.row_off[-1])
+
+
 def fnv1a64(*arrays) -> int:
     h = 0xCBF29CE484222325
     for a in arrays:
@@ -76,7 +81,7 @@ def ssp(g):
     cap = g.cap.copy()
     tc = C.c_int64(0)
     pot = np.zeros(g.n, np.int64)
-    rc = lib().psn_oracle_ssp(C.c_int32(g.n), C.c_int64(2 * g.m), _p(g.row_off, np.int64),
+    rc = lib().psn_oracle_ssp(C.c_int32(g.n), C.c_int64(_m2(g)), _p(g.row_off, np.int64),
                               _p(g.head, np.int32), _p(cap, np.int32), _p(g.cost, np.int32),
                               _p(g.rev, np.int32), _p(g.supply, np.int64), C.byref(tc),
                               _p(pot, np.int64))
@@ -89,7 +94,7 @@ def cost_scaling(g, alpha: int = 12):
     tc = C.c_int64(0)
     price = np.zeros(g.n, np.int64)
     st = Stats()
-    rc = lib().psn_oracle_cost_scaling(C.c_int32(g.n), C.c_int64(2 * g.m), _p(g.row_off, np.int64),
+    rc = lib().psn_oracle_cost_scaling(C.c_int32(g.n), C.c_int64(_m2(g)), _p(g.row_off, np.int64),
                                        _p(g.head, np.int32), _p(cap, np.int32),
                                        _p(g.cost, np.int32), _p(g.rev, np.int32),
                                        _p(g.supply, np.int64), C.c_int32(alpha), C.byref(tc),
@@ -104,7 +109,7 @@ def check(g, cap_final, price_hint=None):
     pot = np.zeros(g.n, np.int64)
     cap_final = np.ascontiguousarray(cap_final, dtype=np.int32)
     hint = None if price_hint is None else _p(np.ascontiguousarray(price_hint, np.int64), np.int64)
-    rc = lib().psn_oracle_check(C.c_int32(g.n), C.c_int64(2 * g.m), _p(g.row_off, np.int64),
+    rc = lib().psn_oracle_check(C.c_int32(g.n), C.c_int64(_m2(g)), _p(g.row_off, np.int64),
                                 _p(g.head, np.int32), _p(g.cap, np.int32), _p(cap_final, np.int32),
                                 _p(g.cost, np.int32), _p(g.rev, np.int32), _p(g.supply, np.int64),
                                 hint, C.byref(tc), _p(pot, np.int64))
@@ -115,6 +120,6 @@ def check_eps(g, cap_final, price, eps: int = 1) -> int:
     """Number of residual arcs violating eps-optimality under scaled prices (-1: eps too big)."""
     cap_final = np.ascontiguousarray(cap_final, dtype=np.int32)
     price = np.ascontiguousarray(price, dtype=np.int64)
-    return int(lib().psn_oracle_check_eps(C.c_int32(g.n), C.c_int64(2 * g.m), _p(g.row_off, np.int64),
+    return int(lib().psn_oracle_check_eps(C.c_int32(g.n), C.c_int64(_m2(g)), _p(g.row_off, np.int64),
                                           _p(g.head, np.int32), _p(cap_final, np.int32),
                                           _p(g.cost, np.int32), _p(price, np.int64), C.c_int64(eps)))

@@ -74,6 +74,7 @@ class Cluster:
     pod_job: np.ndarray    # [P] int32
     slots: int = SLOTS
     k_slots: int = K_SLOTS
+    machine_out: np.ndarray | None = None  # [N] bool: machine taken out (machine -> sink capacity 0)
 
 
 def make_cluster(config_id: int, seed: int, n_machines: int | None = None,
@@ -102,6 +103,64 @@ def make_cluster(config_id: int, seed: int, n_machines: int | None = None,
     req_mem = REQ_MEM_MI[e % 8] * 1024
     return Cluster(N, P, J, cap_cpu, cap_mem, used_cpu, used_mem, req_cpu, req_mem,
                    pod_shape, pod_job)
+
+
+@dataclasses.dataclass
+class Churn:
+    """One round of cluster churn (the incremental configuration): which pods left and what
+    replaced them, which machines report new usage, which machines went away."""
+    pods_replaced: np.ndarray    # [P//20] pod indices, distinct
+    new_shape: np.ndarray
+    new_job: np.ndarray
+    machines_restat: np.ndarray  # [N//20] machine indices, distinct
+    new_used_cpu: np.ndarray
+    new_used_mem: np.ndarray
+    machines_out: np.ndarray     # [N//100] machine indices, distinct
+
+
+def _distinct(draw, count, modulus):
+    seen, out = set(), []
+    while len(out) < count:
+        x = int(draw() % modulus)
+        if x not in seen:
+            seen.add(x)
+            out.append(x)
+    return np.array(out, dtype=np.int64)
+
+
+def churn(cl: Cluster, config_id: int, seed: int, round_no: int = 1):
+    """5 % of the pods leave and as many arrive with fresh (shape, job) draws, 5 % of the
+    machines get fresh usage, 1 % of the machines are taken out.  Stream seed:
+    MAGIC ^ (config_id << 32) ^ seed ^ (0xC3 << 56) ^ (round_no << 40); draw order: replaced pods
+    (rejecting repeats), then (shape, job) per replaced pod, then re-measured machines, then
+    (used_cpu permille, used_mem permille) per such machine, then removed machines.
+    Returns (new Cluster, Churn)."""
+    N, P, J = cl.n_machines, cl.n_pods, cl.n_jobs
+    s = (MAGIC ^ (config_id << 32) ^ seed ^ (0xC3 << 56) ^ (round_no << 40)) & 0xFFFFFFFFFFFFFFFF
+    stream = iter(splitmix64_stream(s, 4 * (P // 20 + N // 20 + N // 100) + 4096).tolist())
+    draw = lambda: next(stream)
+    pods = _distinct(draw, P // 20, P)
+    new_shape = np.empty(pods.shape[0], np.int32)
+    new_job = np.empty(pods.shape[0], np.int32)
+    for i in range(pods.shape[0]):
+        new_shape[i] = draw() % E_SHAPES
+        new_job[i] = draw() % J
+    mach = _distinct(draw, N // 20, N)
+    nuc = np.empty(mach.shape[0], np.int64)
+    num = np.empty(mach.shape[0], np.int64)
+    for i, m in enumerate(mach):
+        nuc[i] = int(cl.cap_cpu[m]) * (draw() % 601) // 1000
+        num[i] = int(cl.cap_mem[m]) * (draw() % 601) // 1000
+    out = _distinct(draw, N // 100, N)
+    new = dataclasses.replace(cl, pod_shape=cl.pod_shape.copy(), pod_job=cl.pod_job.copy(),
+                              used_cpu=cl.used_cpu.copy(), used_mem=cl.used_mem.copy(),
+                              machine_out=(np.zeros(N, bool) if cl.machine_out is None else cl.machine_out.copy()))
+    new.pod_shape[pods] = new_shape
+    new.pod_job[pods] = new_job
+    new.used_cpu[mach] = nuc
+    new.used_mem[mach] = num
+    new.machine_out[out] = True
+    return new, Churn(pods, new_shape, new_job, mach, nuc, num, out)
 
 
 def eval_costs(cl: Cluster):
@@ -184,8 +243,11 @@ def build_graph(cl: Cluster) -> Graph:
     head = np.concatenate([v_ec + cl.pod_shape.astype(np.int64),
                            v_un + cl.pod_job.astype(np.int64), (v_m + m3).ravel(),
                            np.zeros(N, dtype=np.int64), np.zeros(J, dtype=np.int64)])
+    sink_cap = np.full(N, cl.slots, np.int32)
+    if cl.machine_out is not None:
+        sink_cap[cl.machine_out] = 0
     cap = np.concatenate([np.ones(P, np.int32), np.ones(P, np.int32), cap3.ravel(),
-                          np.full(N, cl.slots, np.int32), job_size])
+                          sink_cap, job_size])
     cost = np.concatenate([np.zeros(P, np.int32), np.full(P, C_UNSCHED, np.int32),
                            cost3.ravel(), np.zeros(N, np.int32), np.zeros(J, np.int32)])
     typ = np.concatenate([np.full(P, 1), np.full(P, 2), np.full(E * N * K, 3),

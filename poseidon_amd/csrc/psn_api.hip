@@ -32,7 +32,7 @@ struct psn_ctx {
     // owned device buffers
     std::vector<void *> bufs;
     i64 *d_supply = nullptr;
-    int *d_cost = nullptr, *d_ocap = nullptr;  // non-const aliases of g.cost / g.ocap
+    int *d_cost = nullptr, *d_ocap = nullptr, *d_head = nullptr, *d_rev = nullptr;  // non-const aliases of g.cost / g.ocap / ...
     i64 *d_scalar = nullptr;                   // [0] total cost, [1] max violation, [2..] k_cost_stats output
     unsigned long long *d_tally_out = nullptr;
     int tally_slots = 0;
@@ -263,7 +263,9 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     for (int64_t a = 0; a < m2; ++a) {
         const int32_t r = rev[a];
         if (head[a] < 0 || head[a] >= n) return fail(c, PSN_EINVAL, "head out of range");
-        if (r < 0 || r >= m2 || rev[r] != a || r == a) return fail(c, PSN_EINVAL, "rev is not an involution");
+        if (r < 0 || r >= m2 || rev[r] != a) return fail(c, PSN_EINVAL, "rev is not an involution");
+        if (r == a && (head[a] != tail[(size_t)a] || cap[a] != 0 || cost[a] != 0))
+            return fail(c, PSN_EINVAL, "an arc may pair with itself only as an unused placeholder (self-loop, cap 0, cost 0)");
         if (head[r] != tail[(size_t)a]) return fail(c, PSN_EINVAL, "rev does not point at the reverse arc");
         if (cost[r] != -cost[a]) return fail(c, PSN_EINVAL, "cost[rev[a]] != -cost[a]");
         if (cap[a] < 0) return fail(c, PSN_EINVAL, "negative capacity");
@@ -324,6 +326,7 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     A(g.tally, (size_t)c->tally_slots * kTallyN) A(c->d_tally_out, kTallyN) A(g.ctrl, 1)
     if (std::getenv("PSN_TRACE")) { A(g.dbg, kDbgCap) A(g.dbg_cnt, 1) }
 #undef A
+    c->d_head = d_head; c->d_rev = d_rev;
     g.row = d_row; g.head = d_head; g.cost = c->d_cost; g.rev = d_rev; g.tail = d_tail; g.ocap = c->d_ocap; g.cls = d_cls;
     g.hub_of = d_hub_of; g.hub_vertex = d_hub_vertex; g.nhubs = nhubs;
     hipStream_t s = c->stream;
@@ -345,8 +348,9 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     return PSN_OK;
 }
 
-int psn_eval_costs(psn_ctx *c, const psn_layout *lay, const int64_t *cap_cpu, const int64_t *cap_mem, const int64_t *used_cpu,
-                   const int64_t *used_mem, const int64_t *req_cpu, const int64_t *req_mem, const int64_t *ec_arc_base) {
+static int eval_costs_impl(psn_ctx *c, const psn_layout *lay, const int64_t *cap_cpu, const int64_t *cap_mem, const int64_t *used_cpu,
+                           const int64_t *used_mem, const int64_t *req_cpu, const int64_t *req_mem, const int64_t *ec_arc_base,
+                           int keep_flow) {
     if (!c || !lay || !cap_cpu || !cap_mem || !used_cpu || !used_mem || !req_cpu || !req_mem || !ec_arc_base)
         return fail(c, PSN_EINVAL, "null argument");
     if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
@@ -381,13 +385,98 @@ int psn_eval_costs(psn_ctx *c, const psn_layout *lay, const int64_t *cap_cpu, co
         const int grid = (int)std::min<long long>((total + kBlock - 1) / kBlock, 4096);
         hipLaunchKernelGGL(k_eval_costs, dim3(grid), dim3(kBlock), 0, c->stream, c->g, E, N, K, d, d + N, d + 2 * (size_t)N,
                            d + 3 * (size_t)N, d + 4 * (size_t)N, d + 4 * (size_t)N + E, d + 4 * (size_t)N + 2 * (size_t)E, c->d_cost,
-                           c->d_ocap);
+                           c->d_ocap, keep_flow);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_eval_costs", e);
-    c->solved = false;  // the flow on re-priced arcs was reset
+    if (!keep_flow) c->solved = false;  // the flow on re-priced arcs was reset
+    return PSN_OK;
+}
+
+int psn_eval_costs(psn_ctx *c, const psn_layout *lay, const int64_t *cap_cpu, const int64_t *cap_mem, const int64_t *used_cpu,
+                   const int64_t *used_mem, const int64_t *req_cpu, const int64_t *req_mem, const int64_t *ec_arc_base) {
+    return eval_costs_impl(c, lay, cap_cpu, cap_mem, used_cpu, used_mem, req_cpu, req_mem, ec_arc_base, 0);
+}
+
+int psn_reprice_costs(psn_ctx *c, const psn_layout *lay, const int64_t *cap_cpu, const int64_t *cap_mem, const int64_t *used_cpu,
+                      const int64_t *used_mem, const int64_t *req_cpu, const int64_t *req_mem, const int64_t *ec_arc_base) {
+    return eval_costs_impl(c, lay, cap_cpu, cap_mem, used_cpu, used_mem, req_cpu, req_mem, ec_arc_base, 1);
+}
+
+int psn_patch_arcs(psn_ctx *c, int64_t count, const int64_t *arc_index, const int32_t *head, const int32_t *cap, const int32_t *cost,
+                   const int32_t *rev) {
+    if (!c || count < 0 || (count > 0 && (!arc_index || !head || !cap || !cost || !rev))) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    if (count == 0) return PSN_OK;
+    for (int64_t i = 0; i < count; ++i) {
+        if (arc_index[i] < 0 || arc_index[i] >= c->m2 || rev[i] < 0 || rev[i] >= c->m2 || head[i] < 0 || head[i] >= c->n || cap[i] < 0)
+            return fail(c, PSN_EINVAL, "patched arc out of range");
+        const int64_t ac = cost[i] < 0 ? -(int64_t)cost[i] : cost[i];
+        const long double bound = 8.0L * (long double)c->n * (long double)(ac + 1) * (long double)(c->n + 1);
+        if (bound > 4.0e18L) return fail(c, PSN_EOVERFLOW, "n^2 * |cost| too large for int64 prices");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    // one staging block: indices (8 B) then four int arrays
+    const size_t bytes = (size_t)count * (sizeof(i64) + 4 * sizeof(int)) + sizeof(unsigned);
+    char *d;
+    HIPCHK(c, hipMalloc((void **)&d, bytes));
+    i64 *d_idx = (i64 *)d;
+    int *d_h = (int *)(d + (size_t)count * sizeof(i64)), *d_c = d_h + count, *d_k = d_c + count, *d_r = d_k + count;
+    unsigned *d_bad = (unsigned *)(d_r + count);
+    hipStream_t s = c->stream;
+    hipError_t e = hipMemcpyAsync(d_idx, arc_index, (size_t)count * sizeof(i64), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_h, head, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_c, cap, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_k, cost, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_r, rev, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(unsigned), s);
+    unsigned bad = 0;
+    if (e == hipSuccess) {
+        const int grid = (int)std::min<long long>((count + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(k_patch_arcs, dim3(grid), dim3(kBlock), 0, s, c->g, (long long)count, d_idx, d_h, d_c, d_k, d_r, c->d_head,
+                           c->d_cost, c->d_rev, c->d_ocap);
+        hipLaunchKernelGGL(k_check_patched, dim3(grid), dim3(kBlock), 0, s, c->g, (long long)count, d_idx, d_bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_patch_arcs", e);
+    if (bad) {
+        c->uploaded = c->solved = false;  // the device network is inconsistent: upload again
+        return fail(c, PSN_EINVAL, "patched arcs do not pair up; the network must be uploaded again");
+    }
+    return PSN_OK;
+}
+
+int psn_settle_sources(psn_ctx *c, int64_t count, const int32_t *vertex, int64_t *skipped) {
+    if (!c || count < 0 || (count > 0 && !vertex)) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    if (skipped) *skipped = 0;
+    if (count == 0) return PSN_OK;
+    for (int64_t i = 0; i < count; ++i)
+        if (vertex[i] < 0 || vertex[i] >= c->n) return fail(c, PSN_EINVAL, "vertex out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    char *d;
+    HIPCHK(c, hipMalloc((void **)&d, (size_t)count * sizeof(int) + sizeof(unsigned)));
+    int *d_v = (int *)d;
+    unsigned *d_skip = (unsigned *)(d_v + count);
+    unsigned skip = 0;
+    hipStream_t s = c->stream;
+    hipError_t e = hipMemcpyAsync(d_v, vertex, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_skip, 0, sizeof(unsigned), s);
+    if (e == hipSuccess) {
+        const int grid = (int)std::min<long long>((count + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(k_settle_sources, dim3(grid), dim3(kBlock), 0, s, c->g, (long long)count, d_v, d_skip);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&skip, d_skip, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_settle_sources", e);
+    if (skipped) *skipped = (int64_t)skip;
     return PSN_OK;
 }
 

@@ -853,7 +853,8 @@ __global__ void k_tally_sum(DevGraph g, unsigned long long *out, int nslots) {
 //   cap  = k < fit;  cost = 1000*(used_cpu+(k+1)*req_cpu)/cap_cpu + 1000*(used_mem+(k+1)*req_mem)/cap_mem
 __global__ __launch_bounds__(kBlock) void k_eval_costs(DevGraph g, int E, int N, int K, const i64 *cap_cpu, const i64 *cap_mem,
                                                        const i64 *used_cpu, const i64 *used_mem, const i64 *req_cpu,
-                                                       const i64 *req_mem, const i64 *ec_arc_base, int *mcost, int *mocap) {
+                                                       const i64 *req_mem, const i64 *ec_arc_base, int *mcost, int *mocap,
+                                                       int keep_flow) {
     const long long total = (long long)E * N;
     for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
         const int e = (int)(i / N), m = (int)(i % N);
@@ -867,10 +868,12 @@ __global__ __launch_bounds__(kBlock) void k_eval_costs(DevGraph g, int E, int N,
             const int cp = k < fit ? 1 : 0;
             const unsigned a = a0 + k;
             const int r = g.rev[a];
+            int f = 0;  // flow kept on the arc, cut to the new capacity
+            if (keep_flow) { f = mocap[a] - g.cap[a]; f = f < 0 ? 0 : (f > cp ? cp : f); }
             mcost[a] = (int)c; mcost[r] = -(int)c;
             mocap[a] = cp; mocap[r] = 0;
-            g.cap[a] = cp; g.cap[r] = 0;
-            g.rcap[a] = 0; g.rcap[r] = cp;
+            g.cap[a] = cp - f; g.cap[r] = f;
+            g.rcap[a] = f; g.rcap[r] = cp - f;
         }
     }
 }
@@ -941,6 +944,46 @@ __global__ __launch_bounds__(kBlock) void k_clamp_flow(DevGraph g) {
     for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) {
         const int c = g.cap[a];
         if (c < 0) { g.cap[a] = 0; g.cap[g.rev[a]] += c; }
+    }
+}
+// Overwrite whole residual arcs (head, capacity, cost, pairing); any flow on them is dropped.
+__global__ __launch_bounds__(kBlock) void k_patch_arcs(DevGraph g, long long count, const i64 *idx, const int *nhead, const int *ncap,
+                                                       const int *ncost, const int *nrev, int *mhead, int *mcost, int *mrev, int *mocap) {
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock) {
+        const unsigned a = (unsigned)idx[i];
+        mhead[a] = nhead[i]; mcost[a] = ncost[i]; mrev[a] = nrev[i]; mocap[a] = ncap[i]; g.cap[a] = ncap[i];
+    }
+}
+// Patched arcs must still pair up: rev is an involution onto the reverse arc with the
+// negated cost; an arc may pair with itself only as an unused placeholder (self-loop, no
+// capacity, no cost).  bad[0] counts violations.
+__global__ __launch_bounds__(kBlock) void k_check_patched(DevGraph g, long long count, const i64 *idx, unsigned *bad) {
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock) {
+        const unsigned a = (unsigned)idx[i];
+        const int r = g.rev[a];
+        bool ok = r >= 0 && (unsigned)r < g.m2 && g.head[a] >= 0 && g.head[a] < g.n;
+        if (ok) {
+            if ((unsigned)r == a) ok = g.head[a] == g.tail[a] && g.ocap[a] == 0 && g.cost[a] == 0;
+            else ok = (unsigned)g.rev[r] == a && g.head[r] == g.tail[a] && g.head[a] == g.tail[r] && g.cost[r] == -g.cost[a] &&
+                      g.ocap[a] >= 0 && g.ocap[r] >= 0;
+        }
+        if (!ok) aadd32(bad, 1u);
+    }
+}
+// A vertex that no residual arc enters (a source that has not sent anything yet) can take any
+// price without breaking optimality conditions of other arcs; give it the lowest price that
+// makes all of its own residual arcs non-negative, so a warm start sees no violation there.
+__global__ __launch_bounds__(kBlock) void k_settle_sources(DevGraph g, long long count, const int *vtx, unsigned *skipped) {
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock) {
+        const int v = vtx[i];
+        bool entered = false;
+        i64 best = kNegInf;
+        for (unsigned a = g.row[v]; a < g.row[v + 1]; ++a) {
+            if (g.cap[g.rev[a]] > 0 && (unsigned)g.rev[a] != a) entered = true;
+            if (g.cap[a] > 0) { const i64 key = g.price[g.head[a]] - (i64)g.cost[a] * g.scale; best = key > best ? key : best; }
+        }
+        if (entered) aadd32(skipped, 1u);
+        else if (best != kNegInf) g.price[v] = best;
     }
 }
 __global__ __launch_bounds__(kBlock) void k_scatter_supply(long long count, const int *vtx, const i64 *val, i64 *supply) {

@@ -1,0 +1,720 @@
+// Scheduler service core (include/psn_service.h): task / machine state machine with the
+// reply codes of the Firmament scheduler RPCs, a resident flow network with head-room that
+// is edited in place, and delta generation from consecutive placements.
+//
+// Network layout (vertex ids as psn_layout describes, sized by capacities, not by what is
+// in use): 0 sink | machines | classes | jobs (unscheduled aggregators) | task slots.
+//   sink row      reverse of machine->sink, reverse of job->sink
+//   machine row   reverse of class->machine slot arcs (class-major, slot-minor), machine->sink
+//   class row     `room` reverse places for member tasks, then slot arcs (machine-major)
+//   job row       `room` reverse places for member tasks, then job->sink
+//   task row      task->class, task->job
+// A reverse place that no task uses, and both arcs of a free task slot, are placeholders:
+// self-loops paired with themselves, capacity 0.  A task that arrives takes a free task
+// slot and one free place in its class row and in its job row: four arcs change.
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/psn.h"
+#include "../../include/psn_builder.h"
+#include "../../include/psn_service.h"
+
+namespace {
+
+typedef int64_t i64;
+const i64 kDeadQuantity = (i64)1 << 40;  // capacity == usage: nothing fits on a machine that is not there
+
+enum TaskState { kRunnable = 0, kCompleted = 1, kFailed = 2 };
+
+struct Machine {
+    std::string uuid;
+    i64 cap_cpu = 0, cap_mem = 0, used_cpu = 0, used_mem = 0;
+    bool live = false;
+    uint32_t gen = 0;  // bumped whenever the index changes hands
+};
+struct Pool {  // reverse places of one class or job row
+    i64 first = 0;       // arc index of place 0
+    int room = 0;
+    int count = 0;       // places in use
+    std::vector<int> free_places;
+};
+struct Class {
+    i64 cpu = 0, ram = 0;
+    Pool pool;
+};
+struct Job {
+    std::string uuid;
+    bool used = false;
+    int known = 0;  // tasks of the job the service knows, runnable or not
+    Pool pool;
+};
+struct Task {
+    uint64_t uid = 0;
+    int state = kRunnable;
+    int cls = -1, job = -1;
+    int slot = -1;               // task slot in the network, -1: not in the network
+    i64 place_class = -1, place_job = -1;  // arc indices of its reverse places
+    int machine = -1;            // placement after the last round
+    uint32_t machine_gen = 0;
+    i64 cpu = 0, ram = 0;
+};
+struct Delta { uint64_t uid; int32_t type; int machine; };
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct psn_svc {
+    psn_svc_config cfg{};
+    psn_ctx *ctx = nullptr;
+    std::string err;
+    // entities
+    std::vector<Machine> machines;
+    std::unordered_map<std::string, int> machine_by_uuid;
+    std::vector<int> free_machines;
+    std::vector<Class> classes;
+    std::map<std::pair<i64, i64>, int> class_by_shape;
+    std::vector<Job> jobs;
+    std::unordered_map<std::string, int> job_by_uuid;
+    std::vector<int> free_jobs;
+    std::unordered_map<uint64_t, Task> tasks;
+    std::vector<uint64_t> slot_uid;  // task slot -> uid (0: free)
+    std::vector<char> slot_used;
+    std::vector<Task *> slot_task;   // task slot -> its entry in `tasks` (map nodes do not move)
+    std::vector<int> free_slots;
+    i64 runnable = 0;
+    // network mirror
+    bool laid_out = false, need_layout = true, resident = false;
+    int N = 0, E = 0, J = 0, P = 0, K = 8;
+    psn_layout lay{};
+    int32_t n = 0;
+    i64 m2 = 0;
+    int v_ec = 0, v_un = 0, v_t = 0;
+    std::vector<i64> row_off, supply, ec_arc_base;
+    std::vector<int32_t> head, cap, cost, rev;
+    // changes since the device copy was last in sync
+    std::unordered_set<i64> dirty_arcs;
+    std::unordered_map<i64, int32_t> cap_updates;
+    std::unordered_set<int32_t> dirty_supply;
+    std::vector<int32_t> new_sources;
+    bool reprice = false;
+    // results
+    std::vector<Delta> deltas;
+    psn_svc_stats st{};
+
+    int fail(int code, const std::string &what) { err = what; return code; }
+
+    // ---------------------------------------------------------------- mirror edits
+    void set_arc(i64 a, int h, int cp, int cs, i64 r) {
+        head[(size_t)a] = h; cap[(size_t)a] = cp; cost[(size_t)a] = cs; rev[(size_t)a] = (int32_t)r;
+        if (resident) dirty_arcs.insert(a);
+    }
+    void park(i64 a, int own_vertex) { set_arc(a, own_vertex, 0, 0, a); }
+    void set_cap(i64 a, int cp) {
+        cap[(size_t)a] = cp;
+        if (resident && !dirty_arcs.count(a)) cap_updates[a] = cp;
+    }
+    void set_supply(int v, i64 s) {
+        supply[(size_t)v] = s;
+        if (resident) dirty_supply.insert(v);
+    }
+    i64 take_place(Pool &p) {
+        if (p.free_places.empty()) return -1;
+        const int i = p.free_places.back();
+        p.free_places.pop_back();
+        ++p.count;
+        return p.first + i;
+    }
+    void give_place(Pool &p, i64 arc) {
+        p.free_places.push_back((int)(arc - p.first));
+        --p.count;
+    }
+    i64 job_sink_arc(int j) const { return jobs[(size_t)j].pool.first + jobs[(size_t)j].pool.room; }
+    i64 machine_sink_arc(int m) const { return row_off[(size_t)(1 + m)] + (i64)E * K; }
+
+    // Put a runnable task into the laid-out network; false when some head-room is used up.
+    bool attach(Task &t) {
+        if (free_slots.empty()) return false;
+        Class &c = classes[(size_t)t.cls];
+        Job &jb = jobs[(size_t)t.job];
+        if (c.pool.free_places.empty() || jb.pool.free_places.empty()) return false;
+        t.slot = free_slots.back();
+        free_slots.pop_back();
+        slot_uid[(size_t)t.slot] = t.uid;
+        slot_used[(size_t)t.slot] = 1;
+        slot_task[(size_t)t.slot] = &t;
+        t.place_class = take_place(c.pool);
+        t.place_job = take_place(jb.pool);
+        const int vt = v_t + t.slot;
+        const i64 ta = row_off[(size_t)vt];
+        set_arc(ta, v_ec + t.cls, 1, 0, t.place_class);
+        set_arc(t.place_class, vt, 0, 0, ta);
+        set_arc(ta + 1, v_un + t.job, 1, cfg.unsched_cost, t.place_job);
+        set_arc(t.place_job, vt, 0, -cfg.unsched_cost, ta + 1);
+        set_cap(job_sink_arc(t.job), jb.pool.count);
+        set_supply(vt, 1);
+        set_supply(0, supply[0] - 1);
+        if (resident) new_sources.push_back(vt);
+        return true;
+    }
+    void detach(Task &t) {
+        if (t.slot < 0) return;
+        const int vt = v_t + t.slot;
+        const i64 ta = row_off[(size_t)vt];
+        park(ta, vt);
+        park(ta + 1, vt);
+        park(t.place_class, v_ec + t.cls);
+        park(t.place_job, v_un + t.job);
+        give_place(classes[(size_t)t.cls].pool, t.place_class);
+        give_place(jobs[(size_t)t.job].pool, t.place_job);
+        set_cap(job_sink_arc(t.job), jobs[(size_t)t.job].pool.count);
+        set_supply(vt, 0);
+        set_supply(0, supply[0] + 1);
+        slot_uid[(size_t)t.slot] = 0;
+        slot_used[(size_t)t.slot] = 0;
+        slot_task[(size_t)t.slot] = nullptr;
+        free_slots.push_back(t.slot);
+        t.slot = -1;
+        t.place_class = t.place_job = -1;
+    }
+
+    // ---------------------------------------------------------------- entity tables
+    int class_of(i64 cpu, i64 ram) {
+        auto it = class_by_shape.find({cpu, ram});
+        if (it != class_by_shape.end()) return it->second;
+        const int e = (int)classes.size();
+        Class c;
+        c.cpu = cpu; c.ram = ram;
+        if (laid_out && e < E) {  // an unused class row of the resident network
+            c.pool = spare_class_pool(e);
+            reprice = true;
+        } else {
+            need_layout = true;
+        }
+        classes.push_back(c);
+        class_by_shape[{cpu, ram}] = e;
+        return e;
+    }
+    Pool spare_class_pool(int e) const {
+        Pool p;
+        p.first = row_off[(size_t)(v_ec + e)];
+        p.room = (int)(row_off[(size_t)(v_ec + e + 1)] - p.first - (i64)N * K);
+        for (int i = p.room - 1; i >= 0; --i) p.free_places.push_back(i);
+        return p;
+    }
+    Pool spare_job_pool(int j) const {
+        Pool p;
+        p.first = row_off[(size_t)(v_un + j)];
+        p.room = (int)(row_off[(size_t)(v_un + j + 1)] - p.first - 1);
+        for (int i = p.room - 1; i >= 0; --i) p.free_places.push_back(i);
+        return p;
+    }
+    int job_of(const std::string &uuid) {
+        auto it = job_by_uuid.find(uuid);
+        if (it != job_by_uuid.end()) return it->second;
+        int j;
+        if (!free_jobs.empty()) { j = free_jobs.back(); free_jobs.pop_back(); }
+        else { j = (int)jobs.size(); jobs.emplace_back(); }
+        Job &jb = jobs[(size_t)j];
+        jb.uuid = uuid;
+        jb.used = true;
+        if (laid_out && j < J) jb.pool = spare_job_pool(j);
+        else { jb.pool = Pool(); need_layout = true; }
+        job_by_uuid[uuid] = j;
+        return j;
+    }
+    void release_job_if_empty(int j) {
+        Job &jb = jobs[(size_t)j];
+        if (jb.known > 0) return;
+        job_by_uuid.erase(jb.uuid);
+        jb.uuid.clear();
+        jb.used = false;
+        free_jobs.push_back(j);
+    }
+
+    // ---------------------------------------------------------------- layout
+    // Lay the whole network out again from the entity tables, with fresh head-room.
+    int layout() {
+        const double t0 = now_ms();
+        K = cfg.k_slots;
+        i64 live_tasks = 0;
+        for (auto &kv : tasks) if (kv.second.state == kRunnable) ++live_tasks;
+        auto grown = [](i64 have, i64 floor_) { return (int)std::max<i64>(floor_, have + have / 4 + 1); };
+        N = grown((i64)machines.size(), std::max(cfg.max_machines, 1));
+        E = std::max<int>(cfg.max_classes, (int)((classes.size() + 63) / 64 * 64));
+        J = grown((i64)jobs.size(), std::max(cfg.max_jobs, 1));
+        P = grown(live_tasks, std::max(cfg.max_tasks, 1));
+        lay.n_machines = N; lay.n_classes = E; lay.n_jobs = J; lay.n_tasks = P; lay.k_slots = K;
+        v_ec = 1 + N; v_un = 1 + N + E; v_t = 1 + N + E + J;
+        const i64 nn = (i64)1 + N + E + J + P;
+        if (nn > INT32_MAX) return fail(PSN_EOVERFLOW, "too many vertices");
+        n = (int32_t)nn;
+        // members per class / job among runnable tasks
+        std::vector<i64> cnt_e((size_t)E, 0), cnt_j((size_t)J, 0);
+        for (auto &kv : tasks)
+            if (kv.second.state == kRunnable) { ++cnt_e[(size_t)kv.second.cls]; ++cnt_j[(size_t)kv.second.job]; }
+        const i64 avg_job = jobs.empty() ? 16 : std::max<i64>(16, live_tasks / (i64)std::max<size_t>(1, job_by_uuid.size()));
+        row_off.assign((size_t)n + 1, 0);
+        row_off[1] = (i64)N + J;
+        for (int m = 0; m < N; ++m) row_off[(size_t)(1 + m + 1)] = row_off[(size_t)(1 + m)] + (i64)E * K + 1;
+        std::vector<int> room_e((size_t)E), room_j((size_t)J);
+        for (int e = 0; e < E; ++e) {
+            room_e[(size_t)e] = (int)(cnt_e[(size_t)e] + std::max<i64>(64, cnt_e[(size_t)e] / 4));
+            row_off[(size_t)(v_ec + e + 1)] = row_off[(size_t)(v_ec + e)] + room_e[(size_t)e] + (i64)N * K;
+        }
+        for (int j = 0; j < J; ++j) {
+            room_j[(size_t)j] = (int)(cnt_j[(size_t)j] ? cnt_j[(size_t)j] + std::max<i64>(16, cnt_j[(size_t)j] / 4) : avg_job + avg_job / 4);
+            row_off[(size_t)(v_un + j + 1)] = row_off[(size_t)(v_un + j)] + room_j[(size_t)j] + 1;
+        }
+        for (int t = 0; t < P; ++t) row_off[(size_t)(v_t + t + 1)] = row_off[(size_t)(v_t + t)] + 2;
+        m2 = row_off[(size_t)n];
+        if (m2 >= (i64)0x7FFFFFF0) return fail(PSN_EOVERFLOW, "too many arcs");
+        head.assign((size_t)m2, 0); cap.assign((size_t)m2, 0); cost.assign((size_t)m2, 0); rev.assign((size_t)m2, 0);
+        supply.assign((size_t)n, 0);
+        ec_arc_base.assign((size_t)E, 0);
+        resident = false;  // edits below go to the mirror only
+        dirty_arcs.clear(); cap_updates.clear(); dirty_supply.clear(); new_sources.clear();
+        laid_out = true;
+        auto pair_up = [&](i64 a, i64 r, int to, int from, int cp, int cs) {
+            head[(size_t)a] = to; cap[(size_t)a] = cp; cost[(size_t)a] = cs; rev[(size_t)a] = (int32_t)r;
+            head[(size_t)r] = from; cap[(size_t)r] = 0; cost[(size_t)r] = -cs; rev[(size_t)r] = (int32_t)a;
+        };
+        for (int e = 0; e < E; ++e) {
+            const i64 r0 = row_off[(size_t)(v_ec + e)];
+            for (int i = 0; i < room_e[(size_t)e]; ++i) { head[(size_t)(r0 + i)] = v_ec + e; rev[(size_t)(r0 + i)] = (int32_t)(r0 + i); }
+            const i64 base = r0 + room_e[(size_t)e];
+            ec_arc_base[(size_t)e] = base;
+            for (i64 m = 0; m < N; ++m)
+                for (i64 k = 0; k < K; ++k) pair_up(base + m * K + k, row_off[(size_t)(1 + m)] + (i64)e * K + k, (int)(1 + m), v_ec + e, 0, 0);
+            if ((size_t)e < classes.size()) classes[(size_t)e].pool = spare_class_pool(e);
+        }
+        for (int j = 0; j < J; ++j) {
+            const i64 r0 = row_off[(size_t)(v_un + j)];
+            for (int i = 0; i < room_j[(size_t)j]; ++i) { head[(size_t)(r0 + i)] = v_un + j; rev[(size_t)(r0 + i)] = (int32_t)(r0 + i); }
+            pair_up(r0 + room_j[(size_t)j], row_off[0] + N + j, 0, v_un + j, 0, 0);
+            if ((size_t)j < jobs.size()) jobs[(size_t)j].pool = spare_job_pool(j);
+        }
+        for (int m = 0; m < N; ++m) {
+            const bool live = (size_t)m < machines.size() && machines[(size_t)m].live;
+            pair_up(row_off[(size_t)(1 + m)] + (i64)E * K, row_off[0] + m, 0, 1 + m, live ? cfg.slots_per_machine : 0, 0);
+        }
+        slot_uid.assign((size_t)P, 0);
+        slot_used.assign((size_t)P, 0);
+        slot_task.assign((size_t)P, nullptr);
+        free_slots.clear();
+        for (int t = P - 1; t >= 0; --t) {
+            free_slots.push_back(t);
+            const i64 ta = row_off[(size_t)(v_t + t)];
+            head[(size_t)ta] = v_t + t; rev[(size_t)ta] = (int32_t)ta;
+            head[(size_t)(ta + 1)] = v_t + t; rev[(size_t)(ta + 1)] = (int32_t)(ta + 1);
+        }
+        // runnable tasks in uid order, so that a layout is a function of the state alone
+        std::vector<uint64_t> uids;
+        uids.reserve(tasks.size());
+        for (auto &kv : tasks) { kv.second.slot = -1; if (kv.second.state == kRunnable) uids.push_back(kv.first); }
+        std::sort(uids.begin(), uids.end());
+        for (uint64_t u : uids)
+            if (!attach(tasks[u])) return fail(PSN_EINVAL, "internal: fresh layout without room");
+        need_layout = false;
+        reprice = false;
+        ++st.rebuilds;
+        st.build_ms = now_ms() - t0;
+        return PSN_OK;
+    }
+
+    void cost_inputs(std::vector<i64> &cc, std::vector<i64> &cm, std::vector<i64> &uc, std::vector<i64> &um, std::vector<i64> &rc,
+                     std::vector<i64> &rm) const {
+        cc.assign((size_t)N, kDeadQuantity); cm.assign((size_t)N, kDeadQuantity);
+        uc.assign((size_t)N, kDeadQuantity); um.assign((size_t)N, kDeadQuantity);
+        for (size_t m = 0; m < machines.size() && m < (size_t)N; ++m) {
+            const Machine &mc = machines[m];
+            if (!mc.live) continue;
+            cc[m] = mc.cap_cpu; cm[m] = mc.cap_mem;
+            uc[m] = std::min(mc.used_cpu, mc.cap_cpu); um[m] = std::min(mc.used_mem, mc.cap_mem);
+        }
+        rc.assign((size_t)E, 1); rm.assign((size_t)E, 1);
+        for (size_t e = 0; e < classes.size() && e < (size_t)E; ++e) { rc[e] = classes[e].cpu; rm[e] = classes[e].ram; }
+    }
+};
+
+namespace {
+
+int add_runnable(psn_svc *s, Task &t) {
+    ++s->runnable;
+    if (s->laid_out && !s->need_layout) {
+        if (!s->attach(t)) s->need_layout = true;
+    }
+    return PSN_OK;
+}
+void drop_runnable(psn_svc *s, Task &t) {
+    --s->runnable;
+    if (s->laid_out && t.slot >= 0) s->detach(t);
+    t.slot = -1;
+}
+bool bad_uuid(const char *u) { return !u || !*u || std::strlen(u) > 36; }
+
+}  // namespace
+
+extern "C" {
+
+int psn_svc_create(const psn_svc_config *cfg, psn_svc **out) {
+    if (!out) return PSN_EINVAL;
+    *out = nullptr;
+    psn_svc *s = new (std::nothrow) psn_svc();
+    if (!s) return PSN_ENOMEM;
+    if (cfg) s->cfg = *cfg;
+    if (s->cfg.max_classes <= 0) s->cfg.max_classes = PSN_NCLASSES;
+    if (s->cfg.k_slots <= 0) s->cfg.k_slots = PSN_KSLOTS;
+    if (s->cfg.slots_per_machine <= 0) s->cfg.slots_per_machine = PSN_SLOTS;
+    if (s->cfg.unsched_cost <= 0) s->cfg.unsched_cost = PSN_UNSCHED_COST;
+    if (s->cfg.device >= 0) {
+        psn_config sc = s->cfg.solver;
+        sc.device = s->cfg.device;
+        const int rc = psn_create(&sc, &s->ctx);
+        if (rc != PSN_OK) { delete s; return rc; }
+    }
+    *out = s;
+    return PSN_OK;
+}
+
+void psn_svc_destroy(psn_svc *s) {
+    if (!s) return;
+    if (s->ctx) psn_destroy(s->ctx);
+    delete s;
+}
+
+const char *psn_svc_last_error(const psn_svc *s) { return s ? s->err.c_str() : "null service"; }
+
+int psn_svc_task_submitted(psn_svc *s, uint64_t uid, const char *job_uuid, int32_t state, int64_t cpu, int64_t ram) {
+    if (!s || bad_uuid(job_uuid) || uid == 0 || cpu < 0 || ram < 0) return s ? s->fail(PSN_EINVAL, "bad task description") : PSN_EINVAL;
+    if (s->tasks.count(uid)) return PSN_TASK_ALREADY_SUBMITTED;
+    if (state != PSN_TASK_STATE_CREATED) return PSN_TASK_STATE_NOT_CREATED;
+    Task t;
+    t.uid = uid;
+    t.cpu = std::max<i64>(cpu, 1);  // a zero request still takes a slot: price it as the smallest request
+    t.ram = std::max<i64>(ram, 1);
+    t.cls = s->class_of(t.cpu, t.ram);
+    t.job = s->job_of(job_uuid);
+    Task &ref = s->tasks[uid] = t;
+    ++s->jobs[(size_t)t.job].known;
+    add_runnable(s, ref);
+    return PSN_TASK_SUBMITTED_OK;
+}
+
+int psn_svc_task_updated(psn_svc *s, uint64_t uid, const char *job_uuid, int64_t cpu, int64_t ram) {
+    if (!s || bad_uuid(job_uuid) || cpu < 0 || ram < 0) return s ? s->fail(PSN_EINVAL, "bad task description") : PSN_EINVAL;
+    auto it = s->tasks.find(uid);
+    if (it == s->tasks.end()) return PSN_TASK_NOT_FOUND;
+    Task &t = it->second;
+    auto jt = s->job_by_uuid.find(job_uuid);
+    if (jt == s->job_by_uuid.end() || jt->second != t.job) return PSN_TASK_JOB_NOT_FOUND;
+    cpu = std::max<i64>(cpu, 1);
+    ram = std::max<i64>(ram, 1);
+    if (cpu == t.cpu && ram == t.ram) return PSN_TASK_UPDATED_OK;
+    const bool in_network = t.state == kRunnable;
+    if (in_network) drop_runnable(s, t);
+    t.cpu = cpu; t.ram = ram;
+    t.cls = s->class_of(cpu, ram);
+    if (in_network) add_runnable(s, t);
+    return PSN_TASK_UPDATED_OK;
+}
+
+static int task_leaves(psn_svc *s, uint64_t uid, int new_state, int ok_code, bool forget) {
+    if (!s) return PSN_EINVAL;
+    auto it = s->tasks.find(uid);
+    if (it == s->tasks.end()) return PSN_TASK_NOT_FOUND;
+    Task &t = it->second;
+    if (t.job < 0 || (size_t)t.job >= s->jobs.size() || !s->jobs[(size_t)t.job].used) return PSN_TASK_JOB_NOT_FOUND;
+    if (t.state == kRunnable) drop_runnable(s, t);
+    t.state = new_state;
+    t.machine = -1;
+    if (forget) {
+        const int j = t.job;
+        s->tasks.erase(it);
+        --s->jobs[(size_t)j].known;
+        s->release_job_if_empty(j);
+    }
+    return ok_code;
+}
+int psn_svc_task_completed(psn_svc *s, uint64_t uid) { return task_leaves(s, uid, kCompleted, PSN_TASK_COMPLETED_OK, false); }
+int psn_svc_task_failed(psn_svc *s, uint64_t uid) { return task_leaves(s, uid, kFailed, PSN_TASK_FAILED_OK, false); }
+int psn_svc_task_removed(psn_svc *s, uint64_t uid) { return task_leaves(s, uid, kFailed, PSN_TASK_REMOVED_OK, true); }
+int psn_svc_add_task_stats(psn_svc *s, uint64_t uid) {
+    if (!s) return PSN_EINVAL;
+    return s->tasks.count(uid) ? PSN_TASK_UPDATED_OK : PSN_TASK_NOT_FOUND;
+}
+
+int psn_svc_node_added(psn_svc *s, const char *uuid, int64_t cpu, int64_t ram) {
+    if (!s || bad_uuid(uuid) || cpu <= 0 || ram <= 0 || cpu > (i64)4e15 || ram > (i64)4e15)
+        return s ? s->fail(PSN_EINVAL, "bad machine description") : PSN_EINVAL;
+    if (s->machine_by_uuid.count(uuid)) return PSN_NODE_ALREADY_EXISTS;
+    int m;
+    if (!s->free_machines.empty()) { m = s->free_machines.back(); s->free_machines.pop_back(); }
+    else { m = (int)s->machines.size(); s->machines.emplace_back(); }
+    Machine &mc = s->machines[(size_t)m];
+    mc.uuid = uuid; mc.cap_cpu = cpu; mc.cap_mem = ram; mc.used_cpu = mc.used_mem = 0; mc.live = true; ++mc.gen;
+    s->machine_by_uuid[uuid] = m;
+    if (s->laid_out && m < s->N) { s->set_cap(s->machine_sink_arc(m), s->cfg.slots_per_machine); s->reprice = true; }
+    else s->need_layout = true;
+    return PSN_NODE_ADDED_OK;
+}
+
+int psn_svc_node_updated(psn_svc *s, const char *uuid, int64_t cpu, int64_t ram) {
+    if (!s || bad_uuid(uuid) || cpu <= 0 || ram <= 0 || cpu > (i64)4e15 || ram > (i64)4e15)
+        return s ? s->fail(PSN_EINVAL, "bad machine description") : PSN_EINVAL;
+    auto it = s->machine_by_uuid.find(uuid);
+    if (it == s->machine_by_uuid.end()) return PSN_NODE_NOT_FOUND;
+    Machine &mc = s->machines[(size_t)it->second];
+    if (mc.cap_cpu != cpu || mc.cap_mem != ram) { mc.cap_cpu = cpu; mc.cap_mem = ram; s->reprice = true; }
+    return PSN_NODE_UPDATED_OK;
+}
+
+int psn_svc_add_node_stats(psn_svc *s, const char *uuid, int64_t used_cpu, int64_t used_ram) {
+    if (!s || bad_uuid(uuid) || used_cpu < 0 || used_ram < 0) return s ? s->fail(PSN_EINVAL, "bad machine statistics") : PSN_EINVAL;
+    auto it = s->machine_by_uuid.find(uuid);
+    if (it == s->machine_by_uuid.end()) return PSN_NODE_NOT_FOUND;
+    Machine &mc = s->machines[(size_t)it->second];
+    if (mc.used_cpu != used_cpu || mc.used_mem != used_ram) { mc.used_cpu = used_cpu; mc.used_mem = used_ram; s->reprice = true; }
+    return PSN_NODE_UPDATED_OK;
+}
+
+static int node_leaves(psn_svc *s, const char *uuid, int ok_code) {
+    if (!s || bad_uuid(uuid)) return s ? s->fail(PSN_EINVAL, "bad resource uid") : PSN_EINVAL;
+    auto it = s->machine_by_uuid.find(uuid);
+    if (it == s->machine_by_uuid.end()) return PSN_NODE_NOT_FOUND;
+    const int m = it->second;
+    Machine &mc = s->machines[(size_t)m];
+    mc.live = false;
+    mc.uuid.clear();
+    ++mc.gen;  // placements on it no longer count as "previous machine"
+    s->machine_by_uuid.erase(it);
+    s->free_machines.push_back(m);
+    if (s->laid_out && m < s->N) { s->set_cap(s->machine_sink_arc(m), 0); s->reprice = true; }
+    return ok_code;
+}
+int psn_svc_node_failed(psn_svc *s, const char *uuid) { return node_leaves(s, uuid, PSN_NODE_FAILED_OK); }
+int psn_svc_node_removed(psn_svc *s, const char *uuid) { return node_leaves(s, uuid, PSN_NODE_REMOVED_OK); }
+
+int psn_svc_check(const psn_svc *s) {
+    if (!s) return PSN_SERVING_UNKNOWN;
+    return s->ctx ? PSN_SERVING : PSN_NOT_SERVING;
+}
+
+int psn_svc_network_size(psn_svc *s, psn_layout *lay, int32_t *n, int64_t *m2) {
+    if (!s) return PSN_EINVAL;
+    if (!s->laid_out || s->need_layout) { const int rc = s->layout(); if (rc != PSN_OK) return rc; }
+    if (lay) *lay = s->lay;
+    if (n) *n = s->n;
+    if (m2) *m2 = s->m2;
+    return PSN_OK;
+}
+
+int psn_svc_export_network(psn_svc *s, int64_t *row_off, int32_t *head, int32_t *cap, int32_t *cost, int32_t *rev, int64_t *supply,
+                           int64_t *ec_arc_base, int64_t *cap_cpu, int64_t *cap_mem, int64_t *used_cpu, int64_t *used_mem,
+                           int64_t *req_cpu, int64_t *req_mem) {
+    if (!s) return PSN_EINVAL;
+    if (!s->laid_out || s->need_layout) { const int rc = s->layout(); if (rc != PSN_OK) return rc; }
+    auto put64 = [](int64_t *dst, const std::vector<i64> &v) { if (dst) std::copy(v.begin(), v.end(), dst); };
+    auto put32 = [](int32_t *dst, const std::vector<int32_t> &v) { if (dst) std::copy(v.begin(), v.end(), dst); };
+    put64(row_off, s->row_off); put32(head, s->head); put32(cap, s->cap); put32(cost, s->cost); put32(rev, s->rev);
+    put64(supply, s->supply); put64(ec_arc_base, s->ec_arc_base);
+    std::vector<i64> cc, cm, uc, um, rc, rm;
+    s->cost_inputs(cc, cm, uc, um, rc, rm);
+    put64(cap_cpu, cc); put64(cap_mem, cm); put64(used_cpu, uc); put64(used_mem, um); put64(req_cpu, rc); put64(req_mem, rm);
+    return PSN_OK;
+}
+
+int64_t psn_svc_schedule(psn_svc *s) {
+    if (!s) return PSN_EINVAL;
+    if (!s->ctx) return s->fail(PSN_ESTATE, "no device: the service was created with device = -1");
+    ++s->st.rounds;
+    s->st.build_ms = s->st.upload_ms = s->st.update_ms = s->st.solve_ms = s->st.extract_ms = 0;
+    s->st.patched_arcs = s->st.cap_updates = s->st.supply_updates = 0;
+    s->deltas.clear();
+    int rc;
+    if (!s->laid_out || s->need_layout) { if ((rc = s->layout()) != PSN_OK) return rc; }
+    std::vector<i64> cc, cm, uc, um, rq, rm;
+    psn_result res{};
+    bool warm = false;
+    if (!s->resident) {
+        double t0 = now_ms();
+        rc = psn_upload_csr(s->ctx, s->n, s->m2, s->row_off.data(), s->head.data(), s->cap.data(), s->cost.data(), s->rev.data(),
+                            s->supply.data());
+        if (rc != PSN_OK) return s->fail(rc, std::string("upload: ") + psn_last_error(s->ctx));
+        s->cost_inputs(cc, cm, uc, um, rq, rm);
+        rc = psn_eval_costs(s->ctx, &s->lay, cc.data(), cm.data(), uc.data(), um.data(), rq.data(), rm.data(), s->ec_arc_base.data());
+        if (rc != PSN_OK) return s->fail(rc, std::string("eval_costs: ") + psn_last_error(s->ctx));
+        s->st.upload_ms = now_ms() - t0;
+        s->resident = true;
+        s->reprice = false;
+    } else {
+        double t0 = now_ms();
+        if (!s->dirty_arcs.empty()) {
+            std::vector<i64> idx(s->dirty_arcs.begin(), s->dirty_arcs.end());
+            std::sort(idx.begin(), idx.end());
+            std::vector<int32_t> h(idx.size()), c(idx.size()), k(idx.size()), r(idx.size());
+            for (size_t i = 0; i < idx.size(); ++i) {
+                const size_t a = (size_t)idx[i];
+                h[i] = s->head[a]; c[i] = s->cap[a]; k[i] = s->cost[a]; r[i] = s->rev[a];
+            }
+            rc = psn_patch_arcs(s->ctx, (i64)idx.size(), idx.data(), h.data(), c.data(), k.data(), r.data());
+            if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("patch: ") + psn_last_error(s->ctx)); }
+            s->st.patched_arcs = (i64)idx.size();
+        }
+        if (!s->cap_updates.empty()) {
+            std::vector<i64> idx;
+            std::vector<int32_t> cp;
+            for (auto &kv : s->cap_updates)
+                if (!s->dirty_arcs.count(kv.first)) { idx.push_back(kv.first); cp.push_back(s->cap[(size_t)kv.first]); }
+            rc = psn_update_caps(s->ctx, (i64)idx.size(), idx.data(), cp.data());
+            if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("update_caps: ") + psn_last_error(s->ctx)); }
+            s->st.cap_updates = (i64)idx.size();
+        }
+        if (!s->dirty_supply.empty()) {
+            std::vector<int32_t> v(s->dirty_supply.begin(), s->dirty_supply.end());
+            std::vector<i64> sv(v.size());
+            for (size_t i = 0; i < v.size(); ++i) sv[i] = s->supply[(size_t)v[i]];
+            rc = psn_update_supplies(s->ctx, (i64)v.size(), v.data(), sv.data());
+            if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("update_supplies: ") + psn_last_error(s->ctx)); }
+            s->st.supply_updates = (i64)v.size();
+        }
+        if (s->reprice) {
+            s->cost_inputs(cc, cm, uc, um, rq, rm);
+            rc = psn_reprice_costs(s->ctx, &s->lay, cc.data(), cm.data(), uc.data(), um.data(), rq.data(), rm.data(),
+                                   s->ec_arc_base.data());
+            if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("reprice: ") + psn_last_error(s->ctx)); }
+            s->reprice = false;
+        }
+        if (!s->new_sources.empty()) {
+            // a slot may have been taken and given back since: settle only vertices that are sources now
+            std::vector<int32_t> v;
+            for (int32_t x : s->new_sources) if (s->supply[(size_t)x] > 0) v.push_back(x);
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+            int64_t skipped = 0;
+            rc = psn_settle_sources(s->ctx, (i64)v.size(), v.data(), &skipped);
+            if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("settle: ") + psn_last_error(s->ctx)); }
+        }
+        s->dirty_arcs.clear(); s->cap_updates.clear(); s->dirty_supply.clear(); s->new_sources.clear();
+        s->st.update_ms = now_ms() - t0;
+        warm = true;
+    }
+    {
+        const double t0 = now_ms();
+        rc = psn_solve(s->ctx, warm ? PSN_WARM_START : 0u, &res);
+        s->st.solve_ms = now_ms() - t0;
+        if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("solve: ") + psn_last_error(s->ctx)); }
+    }
+    s->st.last_round_warm = warm ? 1 : 0;
+    if (warm) ++s->st.warm_rounds;
+    s->st.total_cost = res.total_cost;
+    // ---- placements -> deltas
+    const double t0 = now_ms();
+    std::vector<int32_t> place((size_t)s->P, -1);
+    rc = psn_get_placements(s->ctx, &s->lay, place.data());
+    if (rc != PSN_OK) return s->fail(rc, std::string("placements: ") + psn_last_error(s->ctx));
+    // Tasks of a class are interchangeable: hand each class's routed units first to the tasks
+    // that already sit on the unit's machine, so that an unchanged optimum yields no deltas.
+    std::vector<std::vector<int>> members((size_t)s->E);
+    for (int t = 0; t < s->P; ++t)
+        if (s->slot_used[(size_t)t]) members[(size_t)s->slot_task[(size_t)t]->cls].push_back(t);
+    i64 placed = 0;
+    std::vector<int32_t> final_place((size_t)s->P, -1);
+    for (int e = 0; e < s->E; ++e) {
+        std::unordered_map<int, int> units;
+        i64 total = 0;
+        for (int t : members[(size_t)e]) if (place[(size_t)t] >= 0) { ++units[place[(size_t)t]]; ++total; }
+        if (!total) continue;
+        std::vector<char> done(members[(size_t)e].size(), 0);
+        for (size_t i = 0; i < members[(size_t)e].size(); ++i) {  // keep what can be kept
+            const Task &tk = *s->slot_task[(size_t)members[(size_t)e][i]];
+            if (tk.machine < 0 || (size_t)tk.machine >= s->machines.size() || s->machines[(size_t)tk.machine].gen != tk.machine_gen) continue;
+            auto it = units.find(tk.machine);
+            if (it == units.end() || it->second == 0) continue;
+            --it->second; --total;
+            final_place[(size_t)members[(size_t)e][i]] = tk.machine;
+            done[i] = 1;
+        }
+        // the rest of the units, machine by machine, to the tasks the solver routed, then to any other
+        std::vector<int> rest;
+        for (auto &kv : units) for (int c = 0; c < kv.second; ++c) rest.push_back(kv.first);
+        std::sort(rest.begin(), rest.end());
+        size_t ri = 0;
+        for (int pass = 0; pass < 2 && ri < rest.size(); ++pass)
+            for (size_t i = 0; i < members[(size_t)e].size() && ri < rest.size(); ++i) {
+                if (done[i]) continue;
+                if (pass == 0 && place[(size_t)members[(size_t)e][i]] < 0) continue;
+                final_place[(size_t)members[(size_t)e][i]] = rest[ri++];
+                done[i] = 1;
+            }
+    }
+    for (int t = 0; t < s->P; ++t) {
+        if (!s->slot_used[(size_t)t]) continue;
+        Task &tk = *s->slot_task[(size_t)t];
+        const bool had = tk.machine >= 0 && (size_t)tk.machine < s->machines.size() && s->machines[(size_t)tk.machine].gen == tk.machine_gen;
+        const int now = final_place[(size_t)t];
+        int type = PSN_DELTA_NOOP;
+        if (!had && now >= 0) type = PSN_DELTA_PLACE;
+        else if (had && now < 0) type = PSN_DELTA_PREEMPT;
+        else if (had && now >= 0 && now != tk.machine) type = PSN_DELTA_MIGRATE;
+        if (type != PSN_DELTA_NOOP || s->cfg.emit_noop) s->deltas.push_back(Delta{tk.uid, type, now >= 0 ? now : (had ? tk.machine : -1)});
+        tk.machine = now;
+        tk.machine_gen = now >= 0 ? s->machines[(size_t)now].gen : 0;
+        if (now >= 0) ++placed;
+    }
+    s->st.extract_ms = now_ms() - t0;
+    s->st.tasks_placed = placed;
+    s->st.tasks_runnable = s->runnable;
+    s->st.machines_live = (i64)s->machine_by_uuid.size();
+    s->st.n = s->n;
+    s->st.m2 = s->m2;
+    return (int64_t)s->deltas.size();
+}
+
+int psn_svc_get_deltas(psn_svc *s, int64_t first, int64_t count, uint64_t *task_uid, int32_t *type, char *resource_uuid) {
+    if (!s || first < 0 || count < 0 || first + count > (int64_t)s->deltas.size()) return s ? s->fail(PSN_EINVAL, "delta range") : PSN_EINVAL;
+    for (int64_t i = 0; i < count; ++i) {
+        const Delta &d = s->deltas[(size_t)(first + i)];
+        if (task_uid) task_uid[i] = d.uid;
+        if (type) type[i] = d.type;
+        if (resource_uuid) {
+            char *dst = resource_uuid + i * 37;
+            std::memset(dst, 0, 37);
+            if (d.type != PSN_DELTA_PREEMPT && d.machine >= 0 && (size_t)d.machine < s->machines.size())
+                std::strncpy(dst, s->machines[(size_t)d.machine].uuid.c_str(), 36);
+        }
+    }
+    return PSN_OK;
+}
+
+int psn_svc_get_stats(const psn_svc *s, psn_svc_stats *out) {
+    if (!s || !out) return PSN_EINVAL;
+    *out = s->st;
+    out->tasks_runnable = s->runnable;
+    out->machines_live = (i64)s->machine_by_uuid.size();
+    return PSN_OK;
+}
+
+int psn_svc_task_placement(psn_svc *s, uint64_t uid, char *resource_uuid) {
+    if (!s || !resource_uuid) return PSN_EINVAL;
+    std::memset(resource_uuid, 0, 37);
+    auto it = s->tasks.find(uid);
+    if (it == s->tasks.end()) return PSN_TASK_NOT_FOUND;
+    const Task &t = it->second;
+    if (t.machine >= 0 && (size_t)t.machine < s->machines.size() && s->machines[(size_t)t.machine].gen == t.machine_gen)
+        std::strncpy(resource_uuid, s->machines[(size_t)t.machine].uuid.c_str(), 36);
+    return PSN_OK;
+}
+
+psn_ctx *psn_svc_solver(psn_svc *s) { return s ? s->ctx : nullptr; }
+
+}  // extern "C"

@@ -20,7 +20,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "psn_synth_v1.json")
 def test_library_exports_every_declared_symbol():
     lib = pa.load_library()
     declared = set()
-    for hdr in ("psn.h", "psn_builder.h"):
+    for hdr in ("psn.h", "psn_builder.h", "psn_service.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         declared |= set(re.findall(r"\b(psn_[a-z0-9_]+)\s*\(", text))
     assert declared, "no declarations found"

@@ -1,0 +1,174 @@
+"""Scheduler service on the GPU: Schedule rounds (cold, then warm after churn) against the
+CPU oracle's optimum of the same cluster built from scratch; deltas follow
+/root/reference/pkg/firmament/scheduling_delta.proto:26-35 and are what
+/root/reference/cmd/poseidon/poseidon.go:36-68 consumes."""
+import collections
+
+import numpy as np
+import pytest
+
+import poseidon_amd as pa
+from poseidon_amd import _lib
+from poseidon_amd.firmament import ChangeType as CT, NodeReplyType as NR, TaskReplyType as TR
+from oracle import capi, synth
+
+from svc_util import apply_churn, exported_graph, feed_cluster, job_uuid, machine_uuid, oracle_cost
+
+pytestmark = pytest.mark.gpu
+
+
+def placement_cost(cl, uids, where):
+    """Cost of a placement under the slot-cost model: tasks of class e on machine m take the
+    machine's cheapest fitting slots (costs grow with the slot index); others pay the
+    unscheduled cost.  Also checks machine slot limits and that every task fits."""
+    cost3, cap3 = capi.eval_costs(cl)
+    cnt = collections.Counter()
+    per_machine = collections.Counter()
+    total = 0
+    for t in range(cl.n_pods):
+        m = where.get(int(uids[t]), -1)
+        if m < 0:
+            total += synth.C_UNSCHED
+            continue
+        cnt[(int(cl.pod_shape[t]), m)] += 1
+        per_machine[m] += 1
+    for (e, m), c in cnt.items():
+        assert c <= int(cap3[e, m].sum()), "more tasks of a class on a machine than fit"
+        total += int(cost3[e, m, :c].sum())
+    for m, c in per_machine.items():
+        assert c <= cl.slots
+        assert cl.machine_out is None or not cl.machine_out[m]
+    return total
+
+
+def machine_index(uuid):
+    return int(uuid[-12:]) if uuid else -1
+
+
+@pytest.mark.parametrize("cfg,seed", [(0, 1), (0, 2), (1, 1)])
+def test_schedule_rounds_cold_then_warm(cfg, seed):
+    cl = synth.make_cluster(cfg, seed)
+    with pa.SchedulerService(device=0) as s:
+        assert s.Check()
+        uids = feed_cluster(s, cl)
+        deltas = s.Schedule()
+        st = s.stats()
+        assert st.total_cost == oracle_cost(cl) and st.last_round_warm == 0 and st.rebuilds == 1
+        assert all(d.type == CT.PLACE for d in deltas) and len(deltas) == st.tasks_placed
+        where = {d.task_id: machine_index(d.resource_id) for d in deltas}
+        assert placement_cost(cl, uids, where) == st.total_cost
+        # nothing changed: the next round reports nothing
+        assert s.Schedule() == [] and s.stats().total_cost == st.total_cost
+        nxt = int(uids.max()) + 1
+        for rnd in (1, 2):
+            old_uids = set(int(u) for u in uids)
+            cl, ch = synth.churn(cl, cfg, seed, rnd)
+            uids = apply_churn(s, cl, ch, uids, nxt)
+            nxt += ch.pods_replaced.shape[0]
+            deltas = s.Schedule()
+            st = s.stats()
+            assert st.last_round_warm == 1 and st.rebuilds == 1, "churn inside the head-room must be applied in place"
+            assert st.total_cost == oracle_cost(cl)
+            live = set(int(u) for u in uids)
+            for d in deltas:
+                assert d.task_id in live
+                if d.task_id not in old_uids:
+                    assert d.type == CT.PLACE
+                if d.type == CT.PREEMPT:
+                    assert d.resource_id == "" and where.get(d.task_id, -1) >= 0
+                    where[d.task_id] = -1
+                else:
+                    if d.type == CT.MIGRATE:
+                        assert where.get(d.task_id, -1) >= 0 and where[d.task_id] != machine_index(d.resource_id)
+                    where[d.task_id] = machine_index(d.resource_id)
+            for u in old_uids - live:
+                where.pop(u, None)
+            # tasks that sat on a machine that went away must have been moved or preempted
+            for u, m in where.items():
+                assert m < 0 or not cl.machine_out[m]
+            assert placement_cost(cl, uids, where) == st.total_cost
+            for u in list(live)[:50]:
+                assert machine_index(s.task_placement(u)) == where.get(u, -1)
+
+
+def test_warm_round_moves_few_tasks():
+    """A warm round after 5 % churn must not reshuffle the cluster: deltas stay a small
+    multiple of what changed."""
+    cl = synth.make_cluster(1, 2)
+    with pa.SchedulerService(device=0) as s:
+        uids = feed_cluster(s, cl)
+        s.Schedule()
+        cl2, ch = synth.churn(cl, 1, 2, 1)
+        uids = apply_churn(s, cl2, ch, uids, int(uids.max()) + 1)
+        deltas = s.Schedule()
+        assert s.stats().total_cost == oracle_cost(cl2)
+        moved = sum(d.type in (CT.MIGRATE, CT.PREEMPT) for d in deltas)
+        assert moved <= cl.n_pods // 4, moved
+
+
+def test_node_failure_and_task_lifecycle():
+    cl = synth.make_cluster(0, 3)
+    with pa.SchedulerService(device=0, emit_noop=True) as s:
+        uids = feed_cluster(s, cl)
+        deltas = s.Schedule()
+        assert len(deltas) == cl.n_pods  # with emit_noop every runnable task is reported
+        where = {d.task_id: machine_index(d.resource_id) for d in deltas if d.type == CT.PLACE}
+        victim = collections.Counter(where.values()).most_common(1)[0][0]
+        on_victim = [u for u, m in where.items() if m == victim]
+        assert s.NodeFailed(machine_uuid(victim)) == NR.NODE_FAILED_OK
+        done = [int(u) for u in uids[:10] if where.get(int(u), -1) not in (-1, victim)]
+        for u in done:
+            assert s.TaskCompleted(u) == TR.TASK_COMPLETED_OK
+        deltas = {d.task_id: d for d in s.Schedule()}
+        assert not any(u in deltas for u in done), "completed tasks are no longer scheduled"
+        for u in on_victim:  # their machine is gone: the previous placement does not count
+            assert deltas[u].type in (CT.PLACE, CT.NOOP)
+            if deltas[u].type == CT.PLACE:
+                assert machine_index(deltas[u].resource_id) != victim
+        # the node comes back; removing the completed tasks is still acknowledged
+        assert s.NodeAdded(machine_uuid(victim), int(cl.cap_cpu[victim]), int(cl.cap_mem[victim])) == NR.NODE_ADDED_OK
+        for u in done:
+            assert s.TaskRemoved(u) == TR.TASK_REMOVED_OK
+        s.Schedule()
+        g, _ = exported_graph(s)
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        assert rc == 0 and tc == s.stats().total_cost
+
+
+def test_patch_arcs_rejects_broken_pairs():
+    cl = pa.synth_cluster(0, 1)
+    net = pa.build_network(cl)
+    with pa.Solver() as sv:
+        sv.upload(net)
+        lib = sv._lib
+        a = int(net.row_off[-2])  # first arc of the last task
+        idx = np.array([a], np.int64)
+        one = lambda v: np.array([v], np.int32)
+        # pairing it with an arc that does not point back must be caught on the device
+        h, c, k, r = one(int(net.head[a])), one(1), one(0), one(int(net.rev[a]) + 1)
+        rc = lib.psn_patch_arcs(sv._ctx, 1, idx.ctypes.data, h.ctypes.data, c.ctypes.data, k.ctypes.data, r.ctypes.data)
+        assert rc == _lib.PSN_EINVAL and b"pair up" in lib.psn_last_error(sv._ctx)
+        with pytest.raises(_lib.PsnError) as e:
+            sv.solve()
+        assert e.value.code == _lib.PSN_ESTATE  # the network has to be uploaded again
+        sv.upload(net)
+        idx = np.array([net.m2], np.int64)
+        rc = lib.psn_patch_arcs(sv._ctx, 1, idx.ctypes.data, h.ctypes.data, c.ctypes.data, k.ctypes.data, r.ctypes.data)
+        assert rc == _lib.PSN_EINVAL and b"out of range" in lib.psn_last_error(sv._ctx)
+        # a consistent patch: park both arcs of the task and its reverse places, then solve
+        ta = a
+        pairs = [ta, ta + 1, int(net.rev[ta]), int(net.rev[ta + 1])]
+        tail = np.repeat(np.arange(net.n), np.diff(net.row_off))
+        idx = np.array(pairs, np.int64)
+        h = np.array([tail[x] for x in pairs], np.int32)
+        z = np.zeros(4, np.int32)
+        r = np.array(pairs, np.int32)
+        assert lib.psn_patch_arcs(sv._ctx, 4, idx.ctypes.data, h.ctypes.data, z.ctypes.data, z.ctypes.data, r.ctypes.data) == 0
+        sv.update_supplies(np.array([net.n - 1, 0], np.int32), np.array([0, -(cl.layout.n_tasks - 1)], np.int64))
+        sv.eval_costs(cl, net)
+        res = sv.solve()
+        # same as the cluster without its last pod
+        ocl = synth.make_cluster(0, 1)
+        ocl = synth.Cluster(ocl.n_machines, ocl.n_pods - 1, ocl.n_jobs, ocl.cap_cpu, ocl.cap_mem, ocl.used_cpu, ocl.used_mem,
+                            ocl.req_cpu, ocl.req_mem, ocl.pod_shape[:-1], ocl.pod_job[:-1])
+        assert res.total_cost == oracle_cost(ocl)

@@ -1,0 +1,126 @@
+"""Scheduler service core without a GPU: reply-code state machine
+(/root/reference/pkg/firmament/firmament_client.go:43-179 lists the replies the client
+accepts) and in-place maintenance of the flow network, checked by solving the exported
+network with the CPU oracle and comparing with the from-scratch network of the same
+cluster."""
+import numpy as np
+import pytest
+
+import poseidon_amd as pa
+from poseidon_amd import _lib
+from poseidon_amd.firmament import NodeReplyType as NR, TaskReplyType as TR
+from oracle import capi, synth
+
+from svc_util import apply_churn, exported_graph, feed_cluster, job_uuid, machine_uuid, oracle_cost
+
+
+def test_reply_codes_follow_the_rpc_contract():
+    with pa.SchedulerService(device=-1) as s:
+        assert not s.Check()  # no device bound: NOT_SERVING
+        assert s.NodeAdded(machine_uuid(0), 8000, 16 << 20) == NR.NODE_ADDED_OK
+        assert s.NodeAdded(machine_uuid(0), 8000, 16 << 20) == NR.NODE_ALREADY_EXISTS
+        assert s.NodeUpdated(machine_uuid(1), 8000, 16 << 20) == NR.NODE_NOT_FOUND
+        assert s.NodeUpdated(machine_uuid(0), 16000, 16 << 20) == NR.NODE_UPDATED_OK
+        assert s.AddNodeStats(machine_uuid(0), 100, 100) == NR.NODE_UPDATED_OK
+        assert s.AddNodeStats(machine_uuid(7), 100, 100) == NR.NODE_NOT_FOUND
+        assert s.NodeFailed(machine_uuid(1)) == NR.NODE_NOT_FOUND
+        assert s.NodeFailed(machine_uuid(0)) == NR.NODE_FAILED_OK
+        assert s.NodeRemoved(machine_uuid(0)) == NR.NODE_NOT_FOUND
+        # a failed node comes back under the same uuid (nodewatcher.go:254-266 forgets it on failure)
+        assert s.NodeAdded(machine_uuid(0), 8000, 16 << 20) == NR.NODE_ADDED_OK
+        assert s.NodeRemoved(machine_uuid(0)) == NR.NODE_REMOVED_OK
+
+        assert s.TaskSubmitted(11, job_uuid(1), 100, 1024) == TR.TASK_SUBMITTED_OK
+        assert s.TaskSubmitted(11, job_uuid(1), 100, 1024) == TR.TASK_ALREADY_SUBMITTED
+        assert s.TaskSubmitted(12, job_uuid(1), 100, 1024, state=2) == TR.TASK_STATE_NOT_CREATED
+        assert s.TaskUpdated(13, job_uuid(1), 100, 1024) == TR.TASK_NOT_FOUND
+        assert s.TaskUpdated(11, job_uuid(9), 100, 1024) == TR.TASK_JOB_NOT_FOUND
+        assert s.TaskUpdated(11, job_uuid(1), 200, 2048) == TR.TASK_UPDATED_OK
+        assert s.AddTaskStats(11) == TR.TASK_UPDATED_OK
+        assert s.TaskCompleted(99) == TR.TASK_NOT_FOUND
+        assert s.TaskCompleted(11) == TR.TASK_COMPLETED_OK
+        # a completed pod is still deleted later (podwatcher.go:279-297): the task must still be known
+        assert s.TaskSubmitted(11, job_uuid(1), 100, 1024) == TR.TASK_ALREADY_SUBMITTED
+        assert s.TaskRemoved(11) == TR.TASK_REMOVED_OK
+        assert s.TaskRemoved(11) == TR.TASK_NOT_FOUND
+        assert s.TaskSubmitted(12, job_uuid(1), 100, 1024) == TR.TASK_SUBMITTED_OK
+        assert s.TaskFailed(12) == TR.TASK_FAILED_OK
+        assert s.TaskFailed(77) == TR.TASK_NOT_FOUND
+        with pytest.raises(_lib.PsnError) as e:
+            s.Schedule()
+        assert e.value.code == _lib.PSN_ESTATE
+
+
+def test_bad_arguments_are_errors_not_replies():
+    with pa.SchedulerService(device=-1) as s:
+        for call in (lambda: s.NodeAdded("", 1000, 1000), lambda: s.NodeAdded("x" * 40, 1000, 1000),
+                     lambda: s.NodeAdded(machine_uuid(0), 0, 1000), lambda: s.TaskSubmitted(0, job_uuid(0), 1, 1),
+                     lambda: s.TaskSubmitted(5, "", 1, 1), lambda: s.TaskSubmitted(5, job_uuid(0), -1, 1)):
+            with pytest.raises(_lib.PsnError) as e:
+                call()
+            assert e.value.code == _lib.PSN_EINVAL
+
+
+def _check_structure(g):
+    a = np.arange(g.rev.shape[0])
+    assert (g.rev[g.rev] == a).all()
+    tail = np.repeat(np.arange(g.n), np.diff(g.row_off))
+    assert (g.head[g.rev] == tail).all()
+    assert (g.cost[g.rev] == -g.cost).all()
+    selfp = g.rev == a
+    assert (g.cap[selfp] == 0).all() and (g.head[selfp] == tail[selfp]).all()
+    assert g.supply.sum() == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_network_kept_in_place_matches_from_scratch(seed):
+    """Feed C0, then two rounds of churn; after each step the oracle's optimum on the service's
+    network equals the optimum of the network built from scratch for the same cluster."""
+    cl = synth.make_cluster(0, seed)
+    with pa.SchedulerService(device=-1) as s:
+        uids = feed_cluster(s, cl)
+        g, ex = exported_graph(s)
+        _check_structure(g)
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        assert rc == 0 and tc == oracle_cost(cl)
+        m2_first = ex["m2"]
+        nxt = int(uids.max()) + 1
+        for rnd in (1, 2):
+            cl, ch = synth.churn(cl, 0, seed, rnd)
+            uids = apply_churn(s, cl, ch, uids, nxt)
+            nxt += ch.pods_replaced.shape[0]
+            g, ex = exported_graph(s)
+            _check_structure(g)
+            assert ex["m2"] == m2_first, "churn within head-room must not lay the network out again"
+            rc, tc, _, _, _ = capi.cost_scaling(g)
+            assert rc == 0 and tc == oracle_cost(cl)
+        assert s.stats().rebuilds == 1
+
+
+def test_running_out_of_room_lays_out_again():
+    cl = synth.make_cluster(0, 3, n_machines=20, n_pods=100)
+    with pa.SchedulerService(device=-1) as s:
+        uids = feed_cluster(s, cl)
+        g, ex = exported_graph(s)
+        n0 = ex["n"]
+        # many more tasks of one shape than the class row has room for, and new machines
+        for i in range(400):
+            assert s.TaskSubmitted(10_000 + i, job_uuid(0), int(cl.req_cpu[5]), int(cl.req_mem[5])) == TR.TASK_SUBMITTED_OK
+        for m in range(20, 60):
+            assert s.NodeAdded(machine_uuid(m), 8000, 32 << 20) == NR.NODE_ADDED_OK
+        g, ex = exported_graph(s)
+        _check_structure(g)
+        assert ex["n"] > n0 and s.stats().rebuilds == 2
+        assert int(g.supply[0]) == -500
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        assert rc == 0
+        # the same cluster described from scratch
+        cl2 = synth.Cluster(60, 500, cl.n_jobs,
+                            np.concatenate([cl.cap_cpu, np.full(40, 8000, np.int64)]),
+                            np.concatenate([cl.cap_mem, np.full(40, 32 << 20, np.int64)]),
+                            np.concatenate([cl.used_cpu, np.zeros(40, np.int64)]),
+                            np.concatenate([cl.used_mem, np.zeros(40, np.int64)]),
+                            cl.req_cpu, cl.req_mem,
+                            np.concatenate([cl.pod_shape, np.full(400, 5, np.int32)]),
+                            np.concatenate([cl.pod_job, np.zeros(400, np.int32)]))
+        assert tc == oracle_cost(cl2)
