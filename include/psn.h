@@ -156,6 +156,16 @@ int psn_settle_sources(psn_ctx *ctx, int64_t count, const int32_t *vertex, int64
  * (/root/reference/pkg/firmament/firmament_scheduler.proto:17). */
 int psn_solve(psn_ctx *ctx, uint32_t flags, psn_result *out);
 
+/* Solve `count` independent networks, one per context (each uploaded and priced
+ * beforehand, all contexts distinct), with `workers` host threads (0 -> 4) so that the
+ * kernels of several small networks share the GPU through their contexts' streams.
+ * out[i] receives the result of ctxs[i]; the first error code is returned, the other
+ * solves still run.  This is the batch of what-if scheduling rounds: each is the same
+ * Schedule solve (/root/reference/pkg/firmament/firmament_scheduler.proto:17) on its own
+ * cluster state. */
+int psn_solve_batch(psn_ctx *const *ctxs, int32_t count, uint32_t flags, int32_t workers,
+                    psn_result *out);
+
 /* Read back: flow on every residual arc (original minus residual capacity, >= 0 on
  * arcs carrying flow, <= 0 on their pairs), scaled prices (1-optimal for costs
  * multiplied by n+1), and task -> machine index (-1 = unscheduled) for psn-layout

@@ -27,7 +27,7 @@ EXPORTS = [
     "psn_get_flow", "psn_get_residual", "psn_get_prices", "psn_get_costs", "psn_get_placements",
     "psn_placements_device_ptr", "psn_get_placements_device", "psn_kernel_times", "psn_debug_trace",
     "psn_synth_cluster", "psn_network_size", "psn_build_network", "psn_fnv1a64",
-    "psn_reprice_costs", "psn_patch_arcs", "psn_settle_sources",
+    "psn_reprice_costs", "psn_patch_arcs", "psn_settle_sources", "psn_solve_batch",
     "psn_svc_create", "psn_svc_destroy", "psn_svc_last_error", "psn_svc_task_submitted", "psn_svc_task_updated",
     "psn_svc_task_completed", "psn_svc_task_failed", "psn_svc_task_removed", "psn_svc_add_task_stats",
     "psn_svc_node_added", "psn_svc_node_updated", "psn_svc_node_failed", "psn_svc_node_removed",
@@ -89,6 +89,7 @@ def load_library():
     lib.psn_update_caps.argtypes = [vp, i64, vp, vp]
     lib.psn_update_supplies.argtypes = [vp, i64, vp, vp]
     lib.psn_solve.argtypes = [vp, u32, C.POINTER(Result)]
+    lib.psn_solve_batch.argtypes = [vp, i32, u32, i32, vp]
     lib.psn_get_flow.argtypes = [vp, vp]
     lib.psn_get_residual.argtypes = [vp, vp]
     lib.psn_get_prices.argtypes = [vp, vp]

@@ -53,3 +53,22 @@ def all_gather_costs(local: Sequence[int], n_graphs: int, world: int, rank: int,
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view(world, share).t().reshape(-1)
     return [int(x) for x in recv[:n_graphs]]
+
+
+def solve_batch(solvers, warm_start: bool = False, workers: int = 0):
+    """Solve the networks resident in `solvers` (distinct Solver objects, each uploaded and
+    priced) concurrently through psn_solve_batch; returns one SolveResult per solver."""
+    import ctypes as C
+
+    from . import _lib
+    from .solver import SolveResult
+
+    lib = _lib.load_library()
+    n = len(solvers)
+    ctxs = (C.c_void_p * n)(*[s._ctx for s in solvers])
+    out = (_lib.Result * n)()
+    rc = lib.psn_solve_batch(ctxs, n, _lib.PSN_WARM_START if warm_start else 0, workers, out)
+    if rc != _lib.PSN_OK:
+        bad = next((s for s, r in zip(solvers, out) if r.status != _lib.PSN_OK), solvers[0] if solvers else None)
+        _lib.check(rc, bad._ctx if bad is not None else None)
+    return [SolveResult(*(getattr(r, f[0]) for f in _lib.Result._fields_)) for r in out]

@@ -9,6 +9,8 @@
 #include <new>
 #include <string>
 #include <utility>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/psn.h"
@@ -93,6 +95,10 @@ int enqueue_replay(psn_ctx *c, hipStream_t s) {
     int launches = 0;
     const int gv = std::max(1, std::min(kGrid, (g.n + kBlock * kVpt - 1) / (kBlock * kVpt)));  // vertex sweeps
     const int gv1 = std::max(1, std::min(kGrid, (g.n + kBlock - 1) / kBlock));
+    // arc sweeps: enough workgroups for the network, no more (small networks then leave room
+    // for the kernels of other contexts running beside them)
+    int gs = (int)std::max<long long>(32, std::min<long long>(kGrid, (c->m2 + kBlock * 16 - 1) / (kBlock * 16)));
+    if (const char *ev = std::getenv("PSN_GRID")) gs = std::max(1, std::min(kGrid, atoi(ev)));
     const bool timed = (c->cfg.flags & PSN_CFG_KTIME) && !c->gexec;
     auto mark = [&](int cls, bool begin) {
         if (!timed) return;
@@ -113,14 +119,14 @@ int enqueue_replay(psn_ctx *c, hipStream_t s) {
         ++launches;                                                       \
     } while (0)
     hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, g); ++launches;
-    L(PSN_KT_SATURATE, k_saturate, kGrid, g);
+    L(PSN_KT_SATURATE, k_saturate, gs, g);
     L(PSN_KT_OTHER, k_gu_init, gv, g);
-    for (int k = 0; k < kGuIters; ++k) L(PSN_KT_GU_EXPAND, k_gu_expand, kGrid, g, k);
+    for (int k = 0; k < kGuIters; ++k) L(PSN_KT_GU_EXPAND, k_gu_expand, gs, g, k);
     hipLaunchKernelGGL(k_mid, dim3(1), dim3(1), 0, s, g, kGuIters); ++launches;
     L(PSN_KT_OTHER, k_gu_apply, gv1, g);
     L(PSN_KT_RELABEL, k_relabel_compact, gv, g, 0, 0);
     for (int k = 0; k < c->rounds; ++k) {
-        L(PSN_KT_PUSH, k_push, kGrid, g, k);
+        L(PSN_KT_PUSH, k_push, gs, g, k);
         L(PSN_KT_RELABEL, k_relabel_compact, gv, g, k, 1);
     }
     hipLaunchKernelGGL(k_end, dim3(1), dim3(1), 0, s, g, c->rounds); ++launches;
@@ -634,6 +640,31 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     c->solved = status == PSN_OK;
     if (status != PSN_OK) return fail(c, status, "solve did not converge");
     return PSN_OK;
+}
+
+int psn_solve_batch(psn_ctx *const *ctxs, int32_t count, uint32_t flags, int32_t workers, psn_result *out) {
+    if (count < 0 || (count > 0 && (!ctxs || !out))) return PSN_EINVAL;
+    for (int32_t i = 0; i < count; ++i) if (!ctxs[i]) return PSN_EINVAL;
+    for (int32_t i = 0; i < count; ++i)
+        for (int32_t j = i + 1; j < count; ++j)
+            if (ctxs[i] == ctxs[j]) return PSN_EINVAL;  // a context runs one solve at a time
+    if (workers <= 0) workers = 4;
+    workers = std::min<int32_t>(workers, std::max<int32_t>(count, 1));
+    std::atomic<int32_t> next{0};
+    std::atomic<int> first_error{PSN_OK};
+    auto work = [&]() {
+        for (;;) {
+            const int32_t i = next.fetch_add(1);
+            if (i >= count) return;
+            const int rc = psn_solve(ctxs[i], flags, &out[i]);
+            if (rc != PSN_OK) { int expected = PSN_OK; first_error.compare_exchange_strong(expected, rc); }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int32_t w = 1; w < workers; ++w) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    return first_error.load();
 }
 
 int psn_get_flow(psn_ctx *c, int32_t *flow) {

@@ -221,3 +221,28 @@ def test_warm_start_after_capacity_change(solver):
     rc, tc, _, _, _ = capi.cost_scaling(og)
     assert rc == 0 and rw.total_cost == tc
     assert capi.check(og, solver.residual(), solver.prices())[:2] == (0, tc)
+
+
+def test_batch_of_independent_networks_matches_oracle():
+    """Eight small what-if networks solved concurrently (psn_solve_batch): each cost equals the
+    oracle's, and equals a plain sequential solve of the same context."""
+    from poseidon_amd import batch
+    solvers, want = [], []
+    for b in range(8):
+        cl = pa.synth_cluster(0, b + 1, 40 + 5 * b, 300 + 40 * b)
+        net = pa.build_network(cl)
+        s = pa.Solver()
+        s.upload(net)
+        s.eval_costs(cl, net)
+        solvers.append(s)
+        g = synth.build_graph(synth.make_cluster(0, b + 1, 40 + 5 * b, 300 + 40 * b))
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        assert rc == 0
+        want.append(tc)
+    res = batch.solve_batch(solvers, workers=4)
+    assert [r.total_cost for r in res] == want
+    assert all(s.solve().total_cost == w for s, w in zip(solvers, want))
+    with pytest.raises(_lib.PsnError):
+        batch.solve_batch([solvers[0], solvers[0]])
+    for s in solvers:
+        s.close()
