@@ -45,6 +45,26 @@ int psn_build_network(const psn_layout *layout, int32_t slots, int32_t unsched_c
                       int32_t *head, int32_t *cap, int32_t *cost, int32_t *rev, int64_t *supply,
                       int64_t *ec_arc_base);
 
+/* Residual CSR from a plain arc list (0-based ids): rows keep arc-list order, each arc
+ * contributes its forward entry to the row of its tail and its reverse entry (capacity 0,
+ * negated cost) to the row of its head.  Output arrays hold 2m entries, row_off n+1;
+ * fwd_pos (optional, m entries) receives the index of each arc's forward entry. */
+int psn_csr_from_arcs(int32_t n, int64_t m, const int32_t *tail, const int32_t *head, const int32_t *cap,
+                      const int32_t *cost, int64_t *row_off, int32_t *r_head, int32_t *r_cap,
+                      int32_t *r_cost, int32_t *r_rev, int64_t *fwd_pos);
+
+/* DIMACS minimum-cost-flow text ("p min", "n", "a" lines, 1-based ids), the input format of
+ * the CPU solvers Firmament runs (/root/reference/LICENSE:18-26).  psn_dimacs_write emits
+ * one arc per residual arc that has capacity; psn_dimacs_size reads the problem line;
+ * psn_dimacs_read fills an arc list of that size.  Lower bounds are folded away: the
+ * bound is subtracted from the capacity, moved into the supplies, and its cost is returned
+ * in *base_cost (to be added to the optimum of the reduced problem). */
+int psn_dimacs_write(const char *path, int32_t n, int64_t m2, const int64_t *row_off, const int32_t *head,
+                     const int32_t *cap, const int32_t *cost, const int64_t *supply, const char *comment);
+int psn_dimacs_size(const char *path, int32_t *n, int64_t *m);
+int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32_t *head, int32_t *cap,
+                    int32_t *cost, int64_t *supply, int64_t *base_cost);
+
 /* FNV-1a-64 over a byte range, chained through h (start with 0xCBF29CE484222325). */
 uint64_t psn_fnv1a64(const void *data, int64_t nbytes, uint64_t h);
 

@@ -27,6 +27,7 @@ EXPORTS = [
     "psn_get_flow", "psn_get_residual", "psn_get_prices", "psn_get_costs", "psn_get_placements",
     "psn_placements_device_ptr", "psn_get_placements_device", "psn_kernel_times", "psn_debug_trace",
     "psn_synth_cluster", "psn_network_size", "psn_build_network", "psn_fnv1a64",
+    "psn_csr_from_arcs", "psn_dimacs_write", "psn_dimacs_size", "psn_dimacs_read",
     "psn_reprice_costs", "psn_patch_arcs", "psn_settle_sources", "psn_solve_batch",
     "psn_svc_create", "psn_svc_destroy", "psn_svc_last_error", "psn_svc_task_submitted", "psn_svc_task_updated",
     "psn_svc_task_completed", "psn_svc_task_failed", "psn_svc_task_removed", "psn_svc_add_task_stats",
@@ -101,6 +102,10 @@ def load_library():
     lib.psn_synth_cluster.argtypes = [i32, u64, C.POINTER(Layout), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.psn_network_size.argtypes = [C.POINTER(Layout), C.POINTER(i32), C.POINTER(i64)]
     lib.psn_build_network.argtypes = [C.POINTER(Layout), i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.psn_csr_from_arcs.argtypes = [i32, i64] + [vp] * 10
+    lib.psn_dimacs_write.argtypes = [C.c_char_p, i32, i64, vp, vp, vp, vp, vp, C.c_char_p]
+    lib.psn_dimacs_size.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i64)]
+    lib.psn_dimacs_read.argtypes = [C.c_char_p, i32, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
     lib.psn_fnv1a64.restype = u64
     lib.psn_fnv1a64.argtypes = [vp, i64, u64]
     _lib = lib

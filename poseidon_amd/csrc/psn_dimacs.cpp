@@ -1,0 +1,107 @@
+// DIMACS minimum-cost-flow text format, host side (include/psn_builder.h):
+//   p min <vertices> <arcs> / n <vertex> <supply> / a <tail> <head> <low> <cap> <cost>
+// with 1-based vertex ids, and the residual-CSR builder for plain arc lists that a reader
+// needs.  This is the interchange format of the CPU solvers Firmament drives (named at
+// /root/reference/LICENSE:18-26), so a network solved here can be handed to one of them
+// and back.
+#include <algorithm>
+#include <cinttypes>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/psn.h"
+#include "../../include/psn_builder.h"
+
+extern "C" {
+
+int psn_csr_from_arcs(int32_t n, int64_t m, const int32_t *tail, const int32_t *head, const int32_t *cap, const int32_t *cost,
+                      int64_t *row_off, int32_t *r_head, int32_t *r_cap, int32_t *r_cost, int32_t *r_rev, int64_t *fwd_pos) {
+    if (n <= 0 || m < 0 || 2 * m >= (int64_t)0x7FFFFFF0 || !row_off || (m > 0 && (!tail || !head || !cap || !cost || !r_head || !r_cap || !r_cost || !r_rev)))
+        return PSN_EINVAL;
+    std::fill(row_off, row_off + n + 1, (int64_t)0);
+    for (int64_t i = 0; i < m; ++i) {
+        if (tail[i] < 0 || tail[i] >= n || head[i] < 0 || head[i] >= n || cap[i] < 0) return PSN_EINVAL;
+        ++row_off[tail[i] + 1];
+        ++row_off[head[i] + 1];
+    }
+    for (int32_t v = 0; v < n; ++v) row_off[v + 1] += row_off[v];
+    std::vector<int64_t> fill(row_off, row_off + n);
+    for (int64_t i = 0; i < m; ++i) {  // row contents in arc-list order, forward entry and reverse entry alike
+        const int64_t a = fill[tail[i]]++, r = fill[head[i]]++;
+        r_head[a] = head[i]; r_cap[a] = cap[i]; r_cost[a] = cost[i]; r_rev[a] = (int32_t)r;
+        r_head[r] = tail[i]; r_cap[r] = 0; r_cost[r] = -cost[i]; r_rev[r] = (int32_t)a;
+        if (fwd_pos) fwd_pos[i] = a;
+    }
+    return PSN_OK;
+}
+
+int psn_dimacs_write(const char *path, int32_t n, int64_t m2, const int64_t *row_off, const int32_t *head, const int32_t *cap,
+                     const int32_t *cost, const int64_t *supply, const char *comment) {
+    if (!path || n <= 0 || m2 < 0 || !row_off || !supply || (m2 > 0 && (!head || !cap || !cost))) return PSN_EINVAL;
+    FILE *f = std::fopen(path, "w");
+    if (!f) return PSN_EINVAL;
+    int64_t arcs = 0;
+    for (int64_t a = 0; a < m2; ++a) arcs += cap[a] > 0;
+    if (comment) std::fprintf(f, "c %s\n", comment);
+    std::fprintf(f, "p min %d %" PRId64 "\n", n, arcs);
+    for (int32_t v = 0; v < n; ++v)
+        if (supply[v]) std::fprintf(f, "n %d %" PRId64 "\n", v + 1, supply[v]);
+    for (int32_t v = 0; v < n; ++v)
+        for (int64_t a = row_off[v]; a < row_off[v + 1]; ++a)
+            if (cap[a] > 0) std::fprintf(f, "a %d %d 0 %d %d\n", v + 1, head[a] + 1, cap[a], cost[a]);
+    const bool bad = std::ferror(f) != 0;
+    return (std::fclose(f) != 0 || bad) ? PSN_EINVAL : PSN_OK;
+}
+
+int psn_dimacs_size(const char *path, int32_t *n, int64_t *m) {
+    if (!path || !n || !m) return PSN_EINVAL;
+    FILE *f = std::fopen(path, "r");
+    if (!f) return PSN_EINVAL;
+    char line[512];
+    int rc = PSN_EINVAL;
+    while (std::fgets(line, sizeof line, f)) {
+        if (line[0] != 'p') continue;
+        long long nn = 0, mm = 0;
+        char kind[16] = {0};
+        if (std::sscanf(line, "p %15s %lld %lld", kind, &nn, &mm) == 3 && std::strcmp(kind, "min") == 0 && nn > 0 && nn <= INT32_MAX && mm >= 0) {
+            *n = (int32_t)nn; *m = mm; rc = PSN_OK;
+        }
+        break;
+    }
+    std::fclose(f);
+    return rc;
+}
+
+int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32_t *head, int32_t *cap, int32_t *cost,
+                    int64_t *supply, int64_t *base_cost) {
+    if (!path || n <= 0 || m < 0 || !supply || (m > 0 && (!tail || !head || !cap || !cost))) return PSN_EINVAL;
+    FILE *f = std::fopen(path, "r");
+    if (!f) return PSN_EINVAL;
+    std::fill(supply, supply + n, (int64_t)0);
+    int64_t base = 0, got = 0;
+    char line[512];
+    int rc = PSN_OK;
+    while (rc == PSN_OK && std::fgets(line, sizeof line, f)) {
+        if (line[0] == 'n') {
+            long long v = 0, s = 0;
+            if (std::sscanf(line, "n %lld %lld", &v, &s) != 2 || v < 1 || v > n) rc = PSN_EINVAL;
+            else supply[v - 1] = s;
+        } else if (line[0] == 'a') {
+            long long u = 0, v = 0, lo = 0, hi = 0, c = 0;
+            if (std::sscanf(line, "a %lld %lld %lld %lld %lld", &u, &v, &lo, &hi, &c) != 5 || u < 1 || u > n || v < 1 || v > n ||
+                lo < 0 || hi < lo || hi - lo > INT32_MAX || c < -(long long)INT32_MAX || c > INT32_MAX || got >= m) { rc = PSN_EINVAL; break; }
+            // a lower bound is flow that must be there: route it up front
+            supply[u - 1] -= lo; supply[v - 1] += lo; base += lo * c;
+            tail[got] = (int32_t)(u - 1); head[got] = (int32_t)(v - 1); cap[got] = (int32_t)(hi - lo); cost[got] = (int32_t)c;
+            ++got;
+        }
+    }
+    std::fclose(f);
+    if (rc == PSN_OK && got != m) rc = PSN_EINVAL;
+    if (base_cost) *base_cost = base;
+    return rc;
+}
+
+}  // extern "C"
