@@ -125,6 +125,17 @@ int psn_eval_costs(psn_ctx *ctx, const psn_layout *layout, const int64_t *cap_cp
 int psn_update_caps(psn_ctx *ctx, int64_t count, const int64_t *arc_index, const int32_t *new_cap);
 int psn_update_supplies(psn_ctx *ctx, int64_t count, const int32_t *vertex, const int64_t *new_supply);
 
+/* Label selectors as an admission mask: bit (m & 31) of word mask[e * ((N+31)/32) + m/32]
+ * says whether tasks of class e may run on machine m.  Once set, psn_eval_costs and
+ * psn_reprice_costs give the slot arcs of a forbidden (class, machine) pair capacity 0;
+ * NULL lifts the mask.  The mask belongs to the uploaded network and goes away with it.
+ * The reference forwards a pod's nodeSelector as IN_SET selectors
+ * (/root/reference/pkg/k8sclient/podwatcher.go:399,455-465,
+ * /root/reference/pkg/firmament/label_selector.proto:24-35) and node labels
+ * (/root/reference/pkg/k8sclient/nodewatcher.go:309-315); the caller folds the selector
+ * set into the class key and evaluates the match per (class, machine). */
+int psn_set_admission_mask(psn_ctx *ctx, const psn_layout *layout, const uint32_t *mask);
+
 /* Same pricing as psn_eval_costs, for a network that keeps its state between rounds: the
  * flow on every slot arc is kept (cut down to the new capacity), prices and the solved
  * state stay, so the next psn_solve(PSN_WARM_START) repairs instead of starting over.

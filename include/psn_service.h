@@ -77,6 +77,17 @@ typedef struct psn_svc_config {
     psn_config solver;         /* passed to psn_create (device field overwritten) */
 } psn_svc_config;
 
+/* One label selector of a task (/root/reference/pkg/firmament/label_selector.proto:24-35;
+ * type 0 IN_SET, 1 NOT_IN_SET, 2 EXISTS_KEY, 3 NOT_EXISTS_KEY).  The reference sends a pod's
+ * nodeSelector as one IN_SET selector per key
+ * (/root/reference/pkg/k8sclient/podwatcher.go:455-465). */
+typedef struct psn_selector {
+    int32_t type;
+    const char *key;
+    const char *const *values;
+    int32_t n_values;
+} psn_selector;
+
 typedef struct psn_svc_stats {
     int64_t rounds, rebuilds, warm_rounds; /* Schedule calls, full uploads, warm-started solves */
     int64_t patched_arcs, cap_updates, supply_updates; /* records shipped by the last Schedule */
@@ -96,6 +107,12 @@ const char *psn_svc_last_error(const psn_svc *svc);
  * cpu request in millicores and memory request in Kb (podwatcher.go:382-386). */
 int psn_svc_task_submitted(psn_svc *svc, uint64_t task_uid, const char *job_uuid, int32_t state,
                            int64_t cpu_millicores, int64_t ram_kb);
+/* TaskSubmitted with the task's label selectors: the task may only be placed on machines
+ * whose labels satisfy all of them.  Tasks with the same request and the same selectors
+ * share a class. */
+int psn_svc_task_submitted_sel(psn_svc *svc, uint64_t task_uid, const char *job_uuid, int32_t state,
+                               int64_t cpu_millicores, int64_t ram_kb, const psn_selector *selectors,
+                               int32_t n_selectors);
 /* TaskUpdated (:28): same payload; the task may change its request shape. */
 int psn_svc_task_updated(psn_svc *svc, uint64_t task_uid, const char *job_uuid, int64_t cpu_millicores,
                          int64_t ram_kb);
@@ -111,6 +128,11 @@ int psn_svc_node_added(psn_svc *svc, const char *resource_uuid, int64_t cpu_mill
 int psn_svc_node_updated(psn_svc *svc, const char *resource_uuid, int64_t cpu_millicores, int64_t ram_kb);
 int psn_svc_node_failed(psn_svc *svc, const char *resource_uuid);
 int psn_svc_node_removed(psn_svc *svc, const char *resource_uuid);
+/* Labels of a machine as NodeAdded / NodeUpdated carry them
+ * (/root/reference/pkg/k8sclient/nodewatcher.go:309-315): replaces the machine's label set.
+ * Reply as for NodeUpdated. */
+int psn_svc_node_labels(psn_svc *svc, const char *resource_uuid, const char *const *keys,
+                        const char *const *values, int32_t n_labels);
 /* AddNodeStats (:42): resources in use on the machine by anything that is not one of the
  * tasks known to the service; feeds the cost model.  Reply as for NodeUpdated. */
 int psn_svc_add_node_stats(psn_svc *svc, const char *resource_uuid, int64_t used_cpu_millicores, int64_t used_ram_kb);
@@ -137,6 +159,9 @@ int psn_svc_export_network(psn_svc *svc, int64_t *row_off, int32_t *head, int32_
                            int32_t *rev, int64_t *supply, int64_t *ec_arc_base, int64_t *cap_cpu,
                            int64_t *cap_mem, int64_t *used_cpu, int64_t *used_mem, int64_t *req_cpu,
                            int64_t *req_mem);
+/* Admission mask of the resident network as psn_set_admission_mask takes it:
+ * n_classes rows of (n_machines + 31) / 32 words. */
+int psn_svc_export_mask(psn_svc *svc, uint32_t *mask);
 /* Current placement of a task: machine uuid (37 bytes) or empty when unscheduled/unknown. */
 int psn_svc_task_placement(psn_svc *svc, uint64_t task_uid, char *resource_uuid /* 37 */);
 /* The solver context of the service (NULL without a device), for read-backs in tests. */

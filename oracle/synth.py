@@ -75,6 +75,7 @@ class Cluster:
     slots: int = SLOTS
     k_slots: int = K_SLOTS
     machine_out: np.ndarray | None = None  # [N] bool: machine taken out (machine -> sink capacity 0)
+    allowed: np.ndarray | None = None      # [E, N] bool: label selectors of class e admit machine m
 
 
 def make_cluster(config_id: int, seed: int, n_machines: int | None = None,
@@ -181,6 +182,8 @@ def eval_costs(cl: Cluster):
     k1 = np.arange(1, K + 1, dtype=np.int64)[None, None, :]
     fit = np.minimum((cc - uc) // rc, (cm - um) // rm)
     cap = (k1 - 1 < fit).astype(np.int32)
+    if cl.allowed is not None:
+        cap = cap * cl.allowed[:, :, None].astype(np.int32)
     cost = (1000 * (uc + k1 * rc)) // cc + (1000 * (um + k1 * rm)) // cm
     return cost.astype(np.int32), cap
 

@@ -28,12 +28,12 @@ EXPORTS = [
     "psn_placements_device_ptr", "psn_get_placements_device", "psn_kernel_times", "psn_debug_trace",
     "psn_synth_cluster", "psn_network_size", "psn_build_network", "psn_fnv1a64",
     "psn_csr_from_arcs", "psn_dimacs_write", "psn_dimacs_size", "psn_dimacs_read",
-    "psn_reprice_costs", "psn_patch_arcs", "psn_settle_sources", "psn_solve_batch",
+    "psn_set_admission_mask", "psn_reprice_costs", "psn_patch_arcs", "psn_settle_sources", "psn_solve_batch",
     "psn_svc_create", "psn_svc_destroy", "psn_svc_last_error", "psn_svc_task_submitted", "psn_svc_task_updated",
     "psn_svc_task_completed", "psn_svc_task_failed", "psn_svc_task_removed", "psn_svc_add_task_stats",
     "psn_svc_node_added", "psn_svc_node_updated", "psn_svc_node_failed", "psn_svc_node_removed",
     "psn_svc_add_node_stats", "psn_svc_check", "psn_svc_schedule", "psn_svc_get_deltas", "psn_svc_get_stats",
-    "psn_svc_network_size", "psn_svc_export_network", "psn_svc_task_placement", "psn_svc_solver",
+    "psn_svc_task_submitted_sel", "psn_svc_node_labels", "psn_svc_export_mask", "psn_svc_network_size", "psn_svc_export_network", "psn_svc_task_placement", "psn_svc_solver",
 ]
 
 
@@ -85,6 +85,7 @@ def load_library():
     lib.psn_upload_csr.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp]
     lib.psn_eval_costs.argtypes = [vp, C.POINTER(Layout), vp, vp, vp, vp, vp, vp, vp]
     lib.psn_reprice_costs.argtypes = [vp, C.POINTER(Layout), vp, vp, vp, vp, vp, vp, vp]
+    lib.psn_set_admission_mask.argtypes = [vp, C.POINTER(Layout), vp]
     lib.psn_patch_arcs.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     lib.psn_settle_sources.argtypes = [vp, i64, vp, C.POINTER(i64)]
     lib.psn_update_caps.argtypes = [vp, i64, vp, vp]

@@ -38,6 +38,9 @@ struct psn_ctx {
     i64 *d_scalar = nullptr;                   // [0] total cost, [1] max violation, [2..] k_cost_stats output
     unsigned long long *d_tally_out = nullptr;
     int tally_slots = 0;
+    // class x machine admission mask (label selectors), applied by the cost kernel when set
+    unsigned *d_allow = nullptr;
+    int allow_words = 0, allow_classes = 0;
     // placements scratch
     int *d_place = nullptr, *d_slot_machine = nullptr;
     long long place_count = 0, slot_stride = 0, slot_classes = 0;
@@ -86,6 +89,7 @@ void free_graph_buffers(psn_ctx *c) {
     c->bufs.clear();
     c->uploaded = c->solved = false;
     c->d_place = c->d_slot_machine = nullptr;
+    c->d_allow = nullptr; c->allow_words = c->allow_classes = 0;
     c->place_count = c->slot_stride = c->slot_classes = 0;
 }
 
@@ -391,7 +395,8 @@ static int eval_costs_impl(psn_ctx *c, const psn_layout *lay, const int64_t *cap
         const int grid = (int)std::min<long long>((total + kBlock - 1) / kBlock, 4096);
         hipLaunchKernelGGL(k_eval_costs, dim3(grid), dim3(kBlock), 0, c->stream, c->g, E, N, K, d, d + N, d + 2 * (size_t)N,
                            d + 3 * (size_t)N, d + 4 * (size_t)N, d + 4 * (size_t)N + E, d + 4 * (size_t)N + 2 * (size_t)E, c->d_cost,
-                           c->d_ocap, keep_flow);
+                           c->d_ocap, keep_flow, (c->d_allow && c->allow_classes == E && c->allow_words == (N + 31) / 32) ? c->d_allow : nullptr,
+                           c->allow_words);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -409,6 +414,25 @@ int psn_eval_costs(psn_ctx *c, const psn_layout *lay, const int64_t *cap_cpu, co
 int psn_reprice_costs(psn_ctx *c, const psn_layout *lay, const int64_t *cap_cpu, const int64_t *cap_mem, const int64_t *used_cpu,
                       const int64_t *used_mem, const int64_t *req_cpu, const int64_t *req_mem, const int64_t *ec_arc_base) {
     return eval_costs_impl(c, lay, cap_cpu, cap_mem, used_cpu, used_mem, req_cpu, req_mem, ec_arc_base, 1);
+}
+
+int psn_set_admission_mask(psn_ctx *c, const psn_layout *lay, const uint32_t *mask) {
+    if (!c || !lay) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    const int N = lay->n_machines, E = lay->n_classes;
+    if (N <= 0 || E <= 0) return fail(c, PSN_EINVAL, "bad layout");
+    if (!mask) { c->allow_classes = 0; return PSN_OK; }  // every class may use every machine again
+    const int words = (N + 31) / 32;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_allow || c->allow_words != words || c->allow_classes != E) {
+        int rc = dalloc(c, &c->d_allow, (size_t)E * words);  // freed with the network's other buffers
+        if (rc != PSN_OK) return rc;
+        c->allow_words = words;
+        c->allow_classes = E;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_allow, mask, (size_t)E * words * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSN_OK;
 }
 
 int psn_patch_arcs(psn_ctx *c, int64_t count, const int64_t *arc_index, const int32_t *head, const int32_t *cap, const int32_t *cost,

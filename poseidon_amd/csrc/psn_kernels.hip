@@ -854,14 +854,15 @@ __global__ void k_tally_sum(DevGraph g, unsigned long long *out, int nslots) {
 __global__ __launch_bounds__(kBlock) void k_eval_costs(DevGraph g, int E, int N, int K, const i64 *cap_cpu, const i64 *cap_mem,
                                                        const i64 *used_cpu, const i64 *used_mem, const i64 *req_cpu,
                                                        const i64 *req_mem, const i64 *ec_arc_base, int *mcost, int *mocap,
-                                                       int keep_flow) {
+                                                       int keep_flow, const unsigned *allow, int allow_words) {
     const long long total = (long long)E * N;
     for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
         const int e = (int)(i / N), m = (int)(i % N);
         const i64 cc = cap_cpu[m], cm = cap_mem[m], uc = used_cpu[m], um = used_mem[m];
         const i64 rc = req_cpu[e], rm = req_mem[e];
         const i64 fc = (cc - uc) / rc, fm = (cm - um) / rm;
-        const i64 fit = fc < fm ? fc : fm;
+        i64 fit = fc < fm ? fc : fm;
+        if (allow && !((allow[(size_t)e * allow_words + (m >> 5)] >> (m & 31)) & 1u)) fit = 0;  // selector mismatch: no capacity
         const unsigned a0 = (unsigned)(ec_arc_base[e] + (i64)m * K);
         for (int k = 0; k < K; ++k) {
             const i64 c = (1000 * (uc + (k + 1) * rc)) / cc + (1000 * (um + (k + 1) * rm)) / cm;

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -33,8 +34,14 @@ const i64 kDeadQuantity = (i64)1 << 40;  // capacity == usage: nothing fits on a
 
 enum TaskState { kRunnable = 0, kCompleted = 1, kFailed = 2 };
 
+struct Selector {  // /root/reference/pkg/firmament/label_selector.proto:24-35
+    int type = 0;
+    std::string key;
+    std::vector<std::string> values;  // sorted
+};
 struct Machine {
     std::string uuid;
+    std::map<std::string, std::string> labels;
     i64 cap_cpu = 0, cap_mem = 0, used_cpu = 0, used_mem = 0;
     bool live = false;
     uint32_t gen = 0;  // bumped whenever the index changes hands
@@ -47,6 +54,7 @@ struct Pool {  // reverse places of one class or job row
 };
 struct Class {
     i64 cpu = 0, ram = 0;
+    std::vector<Selector> selectors;  // all must hold
     Pool pool;
 };
 struct Job {
@@ -82,7 +90,9 @@ struct psn_svc {
     std::unordered_map<std::string, int> machine_by_uuid;
     std::vector<int> free_machines;
     std::vector<Class> classes;
-    std::map<std::pair<i64, i64>, int> class_by_shape;
+    std::map<std::pair<std::pair<i64, i64>, std::string>, int> class_by_shape;  // (cpu, ram, canonical selectors)
+    std::vector<uint32_t> allow;  // admission mask, E rows of (N + 31) / 32 words
+    bool any_selector = false, mask_dirty = false;
     std::vector<Job> jobs;
     std::unordered_map<std::string, int> job_by_uuid;
     std::vector<int> free_jobs;
@@ -188,20 +198,69 @@ struct psn_svc {
     }
 
     // ---------------------------------------------------------------- entity tables
-    int class_of(i64 cpu, i64 ram) {
-        auto it = class_by_shape.find({cpu, ram});
+    static std::string canonical(std::vector<Selector> &sels) {
+        for (auto &x : sels) std::sort(x.values.begin(), x.values.end());
+        std::sort(sels.begin(), sels.end(), [](const Selector &a, const Selector &b) {
+            return std::tie(a.key, a.type, a.values) < std::tie(b.key, b.type, b.values);
+        });
+        std::string out;
+        for (auto &x : sels) {
+            out += (char)('0' + x.type); out += '\x1f'; out += x.key;
+            for (auto &v : x.values) { out += '\x1e'; out += v; }
+            out += '\x1d';
+        }
+        return out;
+    }
+    bool admits(const Class &c, const Machine &m) const {
+        for (const Selector &x : c.selectors) {
+            auto it = m.labels.find(x.key);
+            const bool has = it != m.labels.end();
+            const bool in = has && std::binary_search(x.values.begin(), x.values.end(), it->second);
+            switch (x.type) {
+                case 0: if (!in) return false; break;   // IN_SET
+                case 1: if (in) return false; break;    // NOT_IN_SET
+                case 2: if (!has) return false; break;  // EXISTS_KEY
+                case 3: if (has) return false; break;   // NOT_EXISTS_KEY
+                default: return false;
+            }
+        }
+        return true;
+    }
+    int mask_words() const { return (N + 31) / 32; }
+    void mask_set(int e, int m, bool on) {
+        if (!laid_out || e >= E || m >= N) return;
+        uint32_t &w = allow[(size_t)e * mask_words() + (m >> 5)];
+        const uint32_t bit = 1u << (m & 31), old = w;
+        w = on ? (w | bit) : (w & ~bit);
+        if (w != old) { mask_dirty = true; reprice = true; }
+    }
+    void mask_machine(int m) {  // column of one machine
+        const Machine &mc = machines[(size_t)m];
+        for (size_t e = 0; e < classes.size(); ++e) mask_set((int)e, m, mc.live && admits(classes[e], mc));
+    }
+    void mask_class(int e) {  // row of one class
+        for (size_t m = 0; m < machines.size(); ++m) mask_set(e, (int)m, machines[m].live && admits(classes[(size_t)e], machines[m]));
+    }
+    int class_of(i64 cpu, i64 ram, std::vector<Selector> sels = {}) {
+        const std::string canon = canonical(sels);
+        const auto key = std::make_pair(std::make_pair(cpu, ram), canon);
+        auto it = class_by_shape.find(key);
         if (it != class_by_shape.end()) return it->second;
         const int e = (int)classes.size();
         Class c;
         c.cpu = cpu; c.ram = ram;
-        if (laid_out && e < E) {  // an unused class row of the resident network
+        c.selectors = std::move(sels);
+        if (!c.selectors.empty()) any_selector = true;
+        const bool fits = laid_out && e < E;
+        if (fits) {  // an unused class row of the resident network
             c.pool = spare_class_pool(e);
             reprice = true;
         } else {
             need_layout = true;
         }
         classes.push_back(c);
-        class_by_shape[{cpu, ram}] = e;
+        class_by_shape[key] = e;
+        if (fits) mask_class(e);
         return e;
     }
     Pool spare_class_pool(int e) const {
@@ -324,6 +383,13 @@ struct psn_svc {
         std::sort(uids.begin(), uids.end());
         for (uint64_t u : uids)
             if (!attach(tasks[u])) return fail(PSN_EINVAL, "internal: fresh layout without room");
+        allow.assign((size_t)E * mask_words(), 0u);
+        for (size_t e = 0; e < classes.size(); ++e)
+            for (size_t m = 0; m < machines.size(); ++m)
+                if (machines[m].live && admits(classes[e], machines[m])) allow[e * mask_words() + (m >> 5)] |= 1u << (m & 31);
+        for (size_t e = classes.size(); e < (size_t)E; ++e)  // unused class rows admit everything (they carry no tasks)
+            for (int w = 0; w < mask_words(); ++w) allow[e * mask_words() + w] = ~0u;
+        mask_dirty = any_selector;
         need_layout = false;
         reprice = false;
         ++st.rebuilds;
@@ -394,15 +460,38 @@ void psn_svc_destroy(psn_svc *s) {
 
 const char *psn_svc_last_error(const psn_svc *s) { return s ? s->err.c_str() : "null service"; }
 
+static bool read_selectors(const psn_selector *sels, int32_t n, std::vector<Selector> &out) {
+    if (n < 0 || (n > 0 && !sels)) return false;
+    for (int32_t i = 0; i < n; ++i) {
+        if (sels[i].type < 0 || sels[i].type > 3 || !sels[i].key || sels[i].n_values < 0 || (sels[i].n_values > 0 && !sels[i].values)) return false;
+        Selector x;
+        x.type = sels[i].type;
+        x.key = sels[i].key;
+        for (int32_t v = 0; v < sels[i].n_values; ++v) {
+            if (!sels[i].values[v]) return false;
+            x.values.emplace_back(sels[i].values[v]);
+        }
+        out.push_back(std::move(x));
+    }
+    return true;
+}
+
 int psn_svc_task_submitted(psn_svc *s, uint64_t uid, const char *job_uuid, int32_t state, int64_t cpu, int64_t ram) {
+    return psn_svc_task_submitted_sel(s, uid, job_uuid, state, cpu, ram, nullptr, 0);
+}
+
+int psn_svc_task_submitted_sel(psn_svc *s, uint64_t uid, const char *job_uuid, int32_t state, int64_t cpu, int64_t ram,
+                               const psn_selector *sels, int32_t n_sels) {
     if (!s || bad_uuid(job_uuid) || uid == 0 || cpu < 0 || ram < 0) return s ? s->fail(PSN_EINVAL, "bad task description") : PSN_EINVAL;
+    std::vector<Selector> selectors;
+    if (!read_selectors(sels, n_sels, selectors)) return s->fail(PSN_EINVAL, "bad label selector");
     if (s->tasks.count(uid)) return PSN_TASK_ALREADY_SUBMITTED;
     if (state != PSN_TASK_STATE_CREATED) return PSN_TASK_STATE_NOT_CREATED;
     Task t;
     t.uid = uid;
     t.cpu = std::max<i64>(cpu, 1);  // a zero request still takes a slot: price it as the smallest request
     t.ram = std::max<i64>(ram, 1);
-    t.cls = s->class_of(t.cpu, t.ram);
+    t.cls = s->class_of(t.cpu, t.ram, std::move(selectors));
     t.job = s->job_of(job_uuid);
     Task &ref = s->tasks[uid] = t;
     ++s->jobs[(size_t)t.job].known;
@@ -423,7 +512,7 @@ int psn_svc_task_updated(psn_svc *s, uint64_t uid, const char *job_uuid, int64_t
     const bool in_network = t.state == kRunnable;
     if (in_network) drop_runnable(s, t);
     t.cpu = cpu; t.ram = ram;
-    t.cls = s->class_of(cpu, ram);
+    t.cls = s->class_of(cpu, ram, s->classes[(size_t)t.cls].selectors);  // the selectors stay
     if (in_network) add_runnable(s, t);
     return PSN_TASK_UPDATED_OK;
 }
@@ -463,7 +552,8 @@ int psn_svc_node_added(psn_svc *s, const char *uuid, int64_t cpu, int64_t ram) {
     Machine &mc = s->machines[(size_t)m];
     mc.uuid = uuid; mc.cap_cpu = cpu; mc.cap_mem = ram; mc.used_cpu = mc.used_mem = 0; mc.live = true; ++mc.gen;
     s->machine_by_uuid[uuid] = m;
-    if (s->laid_out && m < s->N) { s->set_cap(s->machine_sink_arc(m), s->cfg.slots_per_machine); s->reprice = true; }
+    mc.labels.clear();
+    if (s->laid_out && m < s->N) { s->set_cap(s->machine_sink_arc(m), s->cfg.slots_per_machine); s->reprice = true; s->mask_machine(m); }
     else s->need_layout = true;
     return PSN_NODE_ADDED_OK;
 }
@@ -498,11 +588,36 @@ static int node_leaves(psn_svc *s, const char *uuid, int ok_code) {
     ++mc.gen;  // placements on it no longer count as "previous machine"
     s->machine_by_uuid.erase(it);
     s->free_machines.push_back(m);
-    if (s->laid_out && m < s->N) { s->set_cap(s->machine_sink_arc(m), 0); s->reprice = true; }
+    mc.labels.clear();
+    if (s->laid_out && m < s->N) { s->set_cap(s->machine_sink_arc(m), 0); s->reprice = true; s->mask_machine(m); }
     return ok_code;
 }
 int psn_svc_node_failed(psn_svc *s, const char *uuid) { return node_leaves(s, uuid, PSN_NODE_FAILED_OK); }
 int psn_svc_node_removed(psn_svc *s, const char *uuid) { return node_leaves(s, uuid, PSN_NODE_REMOVED_OK); }
+
+int psn_svc_node_labels(psn_svc *s, const char *uuid, const char *const *keys, const char *const *values, int32_t n_labels) {
+    if (!s || bad_uuid(uuid) || n_labels < 0 || (n_labels > 0 && (!keys || !values))) return s ? s->fail(PSN_EINVAL, "bad labels") : PSN_EINVAL;
+    auto it = s->machine_by_uuid.find(uuid);
+    if (it == s->machine_by_uuid.end()) return PSN_NODE_NOT_FOUND;
+    Machine &mc = s->machines[(size_t)it->second];
+    std::map<std::string, std::string> labels;
+    for (int32_t i = 0; i < n_labels; ++i) {
+        if (!keys[i] || !values[i]) return s->fail(PSN_EINVAL, "bad labels");
+        labels[keys[i]] = values[i];
+    }
+    if (labels != mc.labels) {
+        mc.labels.swap(labels);
+        if (s->laid_out && it->second < s->N) s->mask_machine(it->second);
+    }
+    return PSN_NODE_UPDATED_OK;
+}
+
+int psn_svc_export_mask(psn_svc *s, uint32_t *mask) {
+    if (!s || !mask) return PSN_EINVAL;
+    if (!s->laid_out || s->need_layout) { const int rc = s->layout(); if (rc != PSN_OK) return rc; }
+    std::copy(s->allow.begin(), s->allow.end(), mask);
+    return PSN_OK;
+}
 
 int psn_svc_check(const psn_svc *s) {
     if (!s) return PSN_SERVING_UNKNOWN;
@@ -550,6 +665,11 @@ int64_t psn_svc_schedule(psn_svc *s) {
         rc = psn_upload_csr(s->ctx, s->n, s->m2, s->row_off.data(), s->head.data(), s->cap.data(), s->cost.data(), s->rev.data(),
                             s->supply.data());
         if (rc != PSN_OK) return s->fail(rc, std::string("upload: ") + psn_last_error(s->ctx));
+        if (s->any_selector) {
+            rc = psn_set_admission_mask(s->ctx, &s->lay, s->allow.data());
+            if (rc != PSN_OK) return s->fail(rc, std::string("admission mask: ") + psn_last_error(s->ctx));
+        }
+        s->mask_dirty = false;
         s->cost_inputs(cc, cm, uc, um, rq, rm);
         rc = psn_eval_costs(s->ctx, &s->lay, cc.data(), cm.data(), uc.data(), um.data(), rq.data(), rm.data(), s->ec_arc_base.data());
         if (rc != PSN_OK) return s->fail(rc, std::string("eval_costs: ") + psn_last_error(s->ctx));
@@ -587,6 +707,12 @@ int64_t psn_svc_schedule(psn_svc *s) {
             if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("update_supplies: ") + psn_last_error(s->ctx)); }
             s->st.supply_updates = (i64)v.size();
         }
+        if (s->mask_dirty && s->any_selector) {
+            rc = psn_set_admission_mask(s->ctx, &s->lay, s->allow.data());
+            if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("admission mask: ") + psn_last_error(s->ctx)); }
+            s->reprice = true;
+        }
+        s->mask_dirty = false;
         if (s->reprice) {
             s->cost_inputs(cc, cm, uc, um, rq, rm);
             rc = psn_reprice_costs(s->ctx, &s->lay, cc.data(), cm.data(), uc.data(), um.data(), rq.data(), rm.data(),

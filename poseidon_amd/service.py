@@ -35,6 +35,13 @@ class SvcStats(C.Structure):
                 ("total_cost", C.c_int64), ("last_round_warm", C.c_int32)]
 
 
+class Selector(C.Structure):  # include/psn_service.h psn_selector
+    _fields_ = [("type", C.c_int32), ("key", C.c_char_p), ("values", C.POINTER(C.c_char_p)), ("n_values", C.c_int32)]
+
+
+IN_SET, NOT_IN_SET, EXISTS_KEY, NOT_EXISTS_KEY = 0, 1, 2, 3  # /root/reference/pkg/firmament/label_selector.proto:25-30
+
+
 @dataclasses.dataclass
 class SchedulingDelta:  # /root/reference/pkg/firmament/scheduling_delta.proto:25-41
     task_id: int
@@ -56,6 +63,9 @@ def _bind(lib):
     lib.psn_svc_last_error.argtypes = [vp]
     lib.psn_svc_last_error.restype = cp
     lib.psn_svc_task_submitted.argtypes = [vp, u64, cp, i32, i64, i64]
+    lib.psn_svc_task_submitted_sel.argtypes = [vp, u64, cp, i32, i64, i64, C.POINTER(Selector), i32]
+    lib.psn_svc_node_labels.argtypes = [vp, cp, C.POINTER(cp), C.POINTER(cp), i32]
+    lib.psn_svc_export_mask.argtypes = [vp, vp]
     lib.psn_svc_task_updated.argtypes = [vp, u64, cp, i64, i64]
     for name in ("completed", "failed", "removed"):
         getattr(lib, "psn_svc_task_" + name).argtypes = [vp, u64]
@@ -111,7 +121,20 @@ class SchedulerService:
         return enum_type(rc)
 
     # ---- task RPCs
-    def TaskSubmitted(self, uid: int, job_uuid: str, cpu_millicores: int, ram_kb: int, state: int = TASK_STATE_CREATED):
+    def TaskSubmitted(self, uid: int, job_uuid: str, cpu_millicores: int, ram_kb: int, state: int = TASK_STATE_CREATED,
+                      selectors=None):
+        """selectors: iterable of (type, key, [values]) label selectors, e.g. a pod's nodeSelector as
+        [(IN_SET, key, [value]), ...] (/root/reference/pkg/k8sclient/podwatcher.go:455-465)."""
+        if selectors:
+            sels = list(selectors)
+            arr = (Selector * len(sels))()
+            keep = []
+            for i, (typ, key, values) in enumerate(sels):
+                vals = (C.c_char_p * max(1, len(values)))(*[v.encode() for v in values])
+                keep.append(vals)
+                arr[i] = Selector(int(typ), key.encode(), vals, len(values))
+            return self._reply(self._lib.psn_svc_task_submitted_sel(self._svc, uid, job_uuid.encode(), state, cpu_millicores,
+                                                                    ram_kb, arr, len(sels)), TaskReplyType)
         return self._reply(self._lib.psn_svc_task_submitted(self._svc, uid, job_uuid.encode(), state, cpu_millicores, ram_kb),
                            TaskReplyType)
 
@@ -139,6 +162,13 @@ class SchedulerService:
 
     def AddNodeStats(self, uuid: str, used_cpu_millicores: int, used_ram_kb: int):
         return self._reply(self._lib.psn_svc_add_node_stats(self._svc, uuid.encode(), used_cpu_millicores, used_ram_kb), NodeReplyType)
+
+    def NodeLabels(self, uuid: str, labels: dict):
+        """Labels carried by NodeAdded / NodeUpdated (/root/reference/pkg/k8sclient/nodewatcher.go:309-315)."""
+        n = len(labels)
+        keys = (C.c_char_p * max(1, n))(*[k.encode() for k in labels.keys()])
+        vals = (C.c_char_p * max(1, n))(*[v.encode() for v in labels.values()])
+        return self._reply(self._lib.psn_svc_node_labels(self._svc, uuid.encode(), keys, vals, n), NodeReplyType)
 
     def NodeFailed(self, uuid: str):
         return self._reply(self._lib.psn_svc_node_failed(self._svc, uuid.encode()), NodeReplyType)
@@ -193,6 +223,11 @@ class SchedulerService:
         order = ["row_off", "head", "cap", "cost", "rev", "supply", "ec_arc_base", "cap_cpu", "cap_mem", "used_cpu", "used_mem",
                  "req_cpu", "req_mem"]
         _lib.check(self._lib.psn_svc_export_network(self._svc, *[out[k].ctypes.data for k in order]))
+        words = (N + 31) // 32
+        mask = np.empty((E, words), np.uint32)
+        _lib.check(self._lib.psn_svc_export_mask(self._svc, mask.ctypes.data))
+        bits = np.unpackbits(mask.view(np.uint8).reshape(E, words * 4), axis=1, bitorder="little")
+        out["allowed"] = bits[:, :N].astype(bool)
         out["layout"] = lay
         out["n"], out["m2"] = n, m2
         return out

@@ -98,6 +98,20 @@ class Solver:
         new_cap = np.ascontiguousarray(new_cap, np.int32)
         self._chk(self._lib.psn_update_caps(self._ctx, arc_index.shape[0], _vp(arc_index), _vp(new_cap)))
 
+    def set_admission_mask(self, layout, allowed):
+        """allowed: bool [E, N] (class e may use machine m) or None to lift the mask."""
+        if allowed is None:
+            self._chk(self._lib.psn_set_admission_mask(self._ctx, C.byref(layout), None))
+            return
+        allowed = np.asarray(allowed, bool)
+        E, N = allowed.shape
+        words = (N + 31) // 32
+        padded = np.zeros((E, words * 32), bool)
+        padded[:, :N] = allowed
+        mask = np.packbits(padded.reshape(E, words, 32), axis=2, bitorder="little").view(np.uint32).reshape(E, words)
+        mask = np.ascontiguousarray(mask)
+        self._chk(self._lib.psn_set_admission_mask(self._ctx, C.byref(layout), _vp(mask)))
+
     def update_supplies(self, vertex, new_supply):
         vertex = np.ascontiguousarray(vertex, np.int32)
         new_supply = np.ascontiguousarray(new_supply, np.int64)

@@ -59,6 +59,7 @@ def exported_graph(svc):
     cl = synth.Cluster(N, lay.n_tasks, lay.n_jobs, ex["cap_cpu"], ex["cap_mem"], ex["used_cpu"], ex["used_mem"],
                        ex["req_cpu"], ex["req_mem"], np.zeros(0, np.int32), np.zeros(0, np.int32), k_slots=K)
     cost3, cap3 = capi.eval_costs(cl)
+    cap3 = cap3 * ex["allowed"][:, :, None].astype(np.int32)  # label selectors
     idx = (ex["ec_arc_base"][:, None, None] + (np.arange(N)[None, :, None] * K) + np.arange(K)[None, None, :]).ravel()
     cost, cap, rev = ex["cost"].copy(), ex["cap"].copy(), ex["rev"]
     cost[idx] = cost3.ravel()

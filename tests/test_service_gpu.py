@@ -172,3 +172,59 @@ def test_patch_arcs_rejects_broken_pairs():
         ocl = synth.Cluster(ocl.n_machines, ocl.n_pods - 1, ocl.n_jobs, ocl.cap_cpu, ocl.cap_mem, ocl.used_cpu, ocl.used_mem,
                             ocl.req_cpu, ocl.req_mem, ocl.pod_shape[:-1], ocl.pod_job[:-1])
         assert res.total_cost == oracle_cost(ocl)
+
+
+def test_admission_mask_parity_with_oracle():
+    """K1 with a random class x machine mask: arrays bit-equal to the oracle's, optimum equal."""
+    rng = np.random.default_rng(5)
+    cl = pa.synth_cluster(0, 2)
+    net = pa.build_network(cl)
+    ocl = synth.make_cluster(0, 2)
+    ocl.allowed = rng.random((64, ocl.n_machines)) < 0.3
+    g = synth.build_graph(ocl)
+    with pa.Solver() as sv:
+        sv.upload(net)
+        sv.set_admission_mask(cl.layout, ocl.allowed)
+        sv.eval_costs(cl, net)
+        cost, ocap = sv.costs()
+        assert (cost == g.cost).all() and (ocap == g.cap).all()
+        r = sv.solve()
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        assert rc == 0 and r.total_cost == tc
+        sv.set_admission_mask(cl.layout, None)  # lifted again
+        sv.eval_costs(cl, net)
+        assert sv.solve().total_cost == 558826
+
+
+def test_node_selector_end_to_end():
+    """A pod whose selector matches no node stays unscheduled; one whose selector matches a
+    single node lands there (/root/reference/test/e2e/poseidon_integration.go:417-472)."""
+    from poseidon_amd.service import IN_SET
+    with pa.SchedulerService(device=0) as s:
+        for m in range(6):
+            assert s.NodeAdded(machine_uuid(m), 16000, 64 << 20) == NR.NODE_ADDED_OK
+        assert s.NodeLabels(machine_uuid(4), {"kubernetes.io/hostname": "node-4"}) == NR.NODE_UPDATED_OK
+        for uid in range(1, 21):
+            assert s.TaskSubmitted(uid, job_uuid(0), 500, 1 << 20) == TR.TASK_SUBMITTED_OK
+        assert s.TaskSubmitted(100, job_uuid(1), 500, 1 << 20, selectors=[(IN_SET, "kubernetes.io/hostname", ["node-4"])]) \
+            == TR.TASK_SUBMITTED_OK
+        assert s.TaskSubmitted(101, job_uuid(1), 500, 1 << 20, selectors=[(IN_SET, "kubernetes.io/hostname", ["node-9"])]) \
+            == TR.TASK_SUBMITTED_OK
+        deltas = {d.task_id: d for d in s.Schedule()}
+        assert deltas[100].type == CT.PLACE and machine_index(deltas[100].resource_id) == 4
+        assert 101 not in deltas and s.task_placement(101) == ""
+        assert len(deltas) == 21
+        g, _ = exported_graph(s)
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        assert rc == 0 and tc == s.stats().total_cost
+        # the label appears on a node later: the pending pod is placed by a warm round
+        assert s.NodeLabels(machine_uuid(2), {"kubernetes.io/hostname": "node-9"}) == NR.NODE_UPDATED_OK
+        deltas = {d.task_id: d for d in s.Schedule()}
+        assert s.stats().last_round_warm == 1
+        assert deltas[101].type == CT.PLACE and machine_index(deltas[101].resource_id) == 2
+        # an over-committed pod (request larger than any node) stays unscheduled (:310-408)
+        assert s.TaskSubmitted(102, job_uuid(2), 64000, 1 << 20) == TR.TASK_SUBMITTED_OK
+        assert all(d.task_id != 102 for d in s.Schedule())
+        g, _ = exported_graph(s)
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        assert rc == 0 and tc == s.stats().total_cost

@@ -124,3 +124,39 @@ def test_running_out_of_room_lays_out_again():
                             np.concatenate([cl.pod_shape, np.full(400, 5, np.int32)]),
                             np.concatenate([cl.pod_job, np.zeros(400, np.int32)]))
         assert tc == oracle_cost(cl2)
+
+
+def test_selectors_shape_the_admission_mask():
+    """nodeSelector semantics (/root/reference/test/e2e/poseidon_integration.go:417-472 expects a
+    pod with a non-matching selector to stay pending and a matching one to land on that node):
+    selectors become part of the class key and a per-(class, machine) mask."""
+    from poseidon_amd.service import EXISTS_KEY, IN_SET, NOT_EXISTS_KEY, NOT_IN_SET
+    with pa.SchedulerService(device=-1) as s:
+        for m in range(4):
+            assert s.NodeAdded(machine_uuid(m), 8000, 32 << 20) == NR.NODE_ADDED_OK
+        assert s.NodeLabels(machine_uuid(0), {"zone": "a", "gpu": "yes"}) == NR.NODE_UPDATED_OK
+        assert s.NodeLabels(machine_uuid(1), {"zone": "b"}) == NR.NODE_UPDATED_OK
+        assert s.NodeLabels(machine_uuid(9), {"zone": "b"}) == NR.NODE_NOT_FOUND
+        sub = lambda uid, sel: s.TaskSubmitted(uid, job_uuid(0), 100, 1 << 20, selectors=sel)
+        assert sub(1, None) == TR.TASK_SUBMITTED_OK
+        assert sub(2, [(IN_SET, "zone", ["a"])]) == TR.TASK_SUBMITTED_OK
+        assert sub(3, [(IN_SET, "zone", ["b", "a"])]) == TR.TASK_SUBMITTED_OK
+        assert sub(4, [(NOT_IN_SET, "zone", ["a"])]) == TR.TASK_SUBMITTED_OK
+        assert sub(5, [(EXISTS_KEY, "gpu", [])]) == TR.TASK_SUBMITTED_OK
+        assert sub(6, [(NOT_EXISTS_KEY, "zone", []), (NOT_EXISTS_KEY, "gpu", [])]) == TR.TASK_SUBMITTED_OK
+        assert sub(7, [(IN_SET, "zone", ["a", "b"])]) == TR.TASK_SUBMITTED_OK  # same class as task 3
+        assert sub(8, [(IN_SET, "zone", ["nowhere"])]) == TR.TASK_SUBMITTED_OK
+        ex = s.export_network()
+        al = ex["allowed"][:, :4]
+        want = {0: [1, 1, 1, 1], 1: [1, 0, 0, 0], 2: [1, 1, 0, 0], 3: [0, 1, 1, 1], 4: [1, 0, 0, 0], 5: [0, 0, 1, 1],
+                6: [0, 0, 0, 0]}
+        for e, row in want.items():
+            assert al[e].astype(int).tolist() == row, (e, al[e])
+        # labels change in place: machine 2 joins zone a
+        assert s.NodeLabels(machine_uuid(2), {"zone": "a"}) == NR.NODE_UPDATED_OK
+        al = s.export_network()["allowed"][:, :4]
+        assert al[1].astype(int).tolist() == [1, 0, 1, 0] and al[5].astype(int).tolist() == [0, 0, 0, 1]
+        g, _ = exported_graph(s)
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        assert rc == 0 and tc >= synth.C_UNSCHED  # task 8 can go nowhere: it pays the unscheduled cost
+        assert tc < 2 * synth.C_UNSCHED
