@@ -39,6 +39,22 @@ def algorithmic_bytes(r, kind):
     return r.algorithmic_bytes
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in KiB per dispatch; FETCH_SIZE doubled, as gfx950 tallies 128-byte
+    read requests as 64 bytes).  None when no profile is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_write.csv")))
+    if not files:
+        return None, None
+    for row in csv.DictReader(open(files[-1])):
+        if row["kernel"].endswith(kernel):
+            f, w = float(row["FETCH_SIZE_per_dispatch"]), float(row["WRITE_SIZE_per_dispatch"])
+            return int((2 * f + w) * 1024), os.path.basename(files[-1])
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,8 +146,10 @@ def main():
         if dom_ms > 0 and dom_calls > 0:
             bytes_total = algorithmic_bytes(tr, dom)
             achieved = bytes_total / (dom_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic("k_" + dom)
             roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from " + str(traffic_src),
                     "launches": dom_calls, "avg_launch_us": round(dom_ms * 1e3 / dom_calls, 2),
                     "algorithmic_bytes_per_launch": int(bytes_total / dom_calls),
                     "kernel_ms": {k: round(v[0], 2) for k, v in kt.items()}}
