@@ -49,7 +49,7 @@ struct Ctrl {
 //   static:  row[n+1] (u32 offsets), head/cost/rev/tail/ocap[m2], cls[n], hub_of[n]
 //   dynamic: cap[m2] residual capacity, rcap[m2] = cap[rev[a]] (kept in step by every
 //            push so that the global update streams 4 B per arc instead of gathering),
-//            price/excess/cand/dist[n], fstamp[n]
+//            price/excess/cand/dist[n]
 struct DevGraph {
     int n;
     unsigned m2;
@@ -60,9 +60,16 @@ struct DevGraph {
     const int *hub_of;      // hub slot of a vertex, -1 for the rest
     const int *hub_vertex;  // vertex of each hub slot
     int nhubs;
+    // Per hub segment (wave item of a hub row): upper bounds on the largest key
+    // price[head] - cost * S over the segment's residual arcs, so that the push sweep can skip
+    // segments that cannot hold an admissible arc.  seg_scan: value at the segment's last
+    // complete scan; seg_add[p]: keys of arcs that regained capacity during rounds of parity p.
+    const unsigned *hub_row0;  // first arc of each hub's row
+    const int *hub_seg0;       // index of each hub's first segment
+    i64 *seg_scan, *seg_add[2];
+    int n_hub_segs;
     int *cap, *rcap;
     i64 *price, *excess, *cand, *dist;
-    unsigned *fstamp;
     int2 *list_low[2];  // active vertices of degree <= kLowMax (one lane each)
     int4 *list_seg[2];  // active wave items (vertex, arc range, flags)
     int2 *fr_low[3];    // global-update frontier, same split, triple buffered

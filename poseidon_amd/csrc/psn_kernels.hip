@@ -23,7 +23,15 @@ namespace psn {
 
 static constexpr i64 kInf = INT64_MAX;
 static constexpr i64 kNegInf = INT64_MIN;
-static constexpr i64 kDistInf = INT64_MAX / 4;
+// Global-update distances are stored packed: (distance << 16) | stamp of the sweep that last
+// lowered it, so that one atomic min both lowers the distance and tells whether the vertex
+// was already queued during this sweep.  Arc lengths are cut at kLenMax: shortest distances
+// under shorter lengths still satisfy d(u) <= d(v) + length(u,v) for the true lengths, which
+// is all the price update needs; with at most 2^28 vertices distances stay below 2^46.
+static constexpr i64 kDistInf = (i64)1 << 46;
+static constexpr i64 kLenMax = (i64)1 << 18;
+__device__ __forceinline__ i64 dist_pack(i64 d, unsigned stamp16) { return (d << 16) | (i64)stamp16; }
+__device__ __forceinline__ i64 dist_of(i64 packed) { return packed >> 16; }
 
 typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -87,13 +95,15 @@ __device__ __forceinline__ int2 low_item(int v, unsigned r0, unsigned r1) { retu
 __device__ __forceinline__ int4 solo_item(int v, unsigned r0, unsigned r1) { return make_int4(v, (int)r0, (int)r1, 1); }
 // A vertex larger than one item: its segments, starting at a per-round rotated one so that
 // vertices with common neighbours do not all begin at the same arcs.
-__device__ __forceinline__ void append_split(unsigned *cnt, int4 *segl, int v, unsigned r0, unsigned r1, unsigned rot) {
+// flags >> 1 = 1 + index of the segment's bound slots when the vertex is a hub (seg1 = 1 + index
+// of its first segment), else 0.
+__device__ __forceinline__ void append_split(unsigned *cnt, int4 *segl, int v, unsigned r0, unsigned r1, unsigned rot, int seg1 = 0) {
     const unsigned nseg = (r1 - r0 + kWSeg - 1) / kWSeg;
     const unsigned base = aadd32(&cnt[kClsSeg], nseg);
     unsigned sg = rot % nseg;
     for (unsigned s = 0; s < nseg; ++s) {
         const unsigned a = r0 + sg * kWSeg;
-        segl[base + s] = make_int4(v, (int)a, (int)min(r1, a + kWSeg), 0);
+        segl[base + s] = make_int4(v, (int)a, (int)min(r1, a + kWSeg), seg1 ? (seg1 + (int)sg) << 1 : 0);
         if (++sg == nseg) sg = 0;
     }
 }
@@ -112,7 +122,7 @@ __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
 template <int VPT>
 __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *segl, const bool (&take)[VPT], const int (&v)[VPT],
                                              const int (&cls)[VPT], const unsigned (&r0)[VPT], const unsigned (&r1)[VPT], unsigned rot,
-                                             unsigned (*lds)[kBlock / 64 + 1]) {
+                                             unsigned (*lds)[kBlock / 64 + 1], const DevGraph *bounds = nullptr) {
     unsigned nl = 0, ns = 0;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) { nl += take[i] && cls[i] == kClsLow; ns += take[i] && cls[i] == kClsMed; }
@@ -133,7 +143,11 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
         if (!take[i]) continue;
         if (cls[i] == kClsLow) lowl[pl++] = low_item(v[i], r0[i], r1[i]);
         else if (cls[i] == kClsMed) segl[ps++] = solo_item(v[i], r0[i], r1[i]);
-        else append_split(cnt, segl, v[i], r0[i], r1[i], rot ^ (unsigned)v[i] * 0x9E3779B9u);  // rare: hubs
+        else {  // rare: hubs
+            int seg1 = 0;
+            if (bounds) { const int h = bounds->hub_of[v[i]]; if (h >= 0) seg1 = bounds->hub_seg0[h] + 1; }
+            append_split(cnt, segl, v[i], r0[i], r1[i], rot ^ (unsigned)v[i] * 0x9E3779B9u, seg1);
+        }
     }
     __syncthreads();
 }
@@ -184,9 +198,30 @@ __device__ __forceinline__ unsigned count9(unsigned a0, unsigned lim8, unsigned 
     return (a0 < lim8 ? min(8u, lim8 - a0) : 0u) + (at < limt ? 1u : 0u);
 }
 
+// Per-vertex values for the 9 arcs of a lane.  Parallel arcs (same head) sit next to each
+// other in a row, so a lane fetches once per run of equal heads among its 8 consecutive
+// arcs and copies the value along; the tail arc (slot 8) is fetched on its own.
+template <typename T, typename F>
+__device__ __forceinline__ void gather9(const int (&hd)[9], const bool (&need)[9], T (&out)[9], T dflt, F load) {
+    bool have[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const bool reuse = j > 0 && j < 8 && have[j > 0 ? j - 1 : 0] && hd[j] == hd[j > 0 ? j - 1 : 0];
+        out[j] = reuse ? out[j > 0 ? j - 1 : 0] : (need[j] ? load(hd[j]) : dflt);
+        have[j] = reuse || need[j];
+    }
+}
+
+// A push over (u,v) makes the reverse arc r = (v,u) residual; if v is a hub, the bound of the
+// segment of v's row that holds r must cover r's key.
+__device__ __forceinline__ void seg_note(const DevGraph &g, int hub, int r, i64 key, int par) {
+    const unsigned s = (unsigned)g.hub_seg0[hub] + ((unsigned)r - g.hub_row0[hub]) / kWSeg;
+    amax64(&g.seg_add[par][s], key);
+}
+
 // --------------------------------------------------------------------------- pushes
 // Low-degree vertex: one lane, all loads of its (at most kLowMax) arcs issued together.
-__device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, int2 it, i64 S, Tally &t) {
+__device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, int2 it, i64 S, int par, Tally &t) {
     const int u = it.x & 0x0FFFFFFF;
     const unsigned deg = (unsigned)it.x >> 28, r0 = (unsigned)it.y;
     const i64 pu = g.price[u];
@@ -209,11 +244,11 @@ __device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, in
             const i64 d = e < cp[j] ? e : cp[j];
             const unsigned a = r0 + j;
             const int r = g.rev[a];
-            const int na = cp[j] - (int)d, nr = g.cap[r] + (int)d;
+            const int na = cp[j] - (int)d, nr = g.rcap[a] + (int)d;
             g.cap[a] = na; g.cap[r] = nr; g.rcap[a] = nr; g.rcap[r] = na;
             const int h = g.hub_of[hd[j]];
             const i64 kr = pu + (i64)cs[j] * S;
-            if (h >= 0) { lds_add(&hb.add[h], d); lds_max(&hb.ext[h], kr); }
+            if (h >= 0) { lds_add(&hb.add[h], d); lds_max(&hb.ext[h], kr); seg_note(g, h, r, kr, par); }
             else { aadd64(&g.excess[hd[j]], d); amax64(&g.cand[hd[j]], kr); }
             e -= d; cp[j] = na;
             t.c[kTallyPushes]++;
@@ -228,12 +263,25 @@ __device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, in
 // several items has its waves claim what they want to push from excess[u] and hand back
 // what was not granted.  `rot` permutes which lane owns which arcs, so that the prefix
 // order (= who gets the excess first) changes from round to round.
-__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int4 it, i64 S, unsigned rot, Tally &t) {
+__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int4 it, i64 S, unsigned rot, int par, Tally &t) {
     const int lane = lane_id();
     const int u = it.x;
     const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
     const bool solo = it.w & 1;
+    const int seg1 = it.w >> 1;  // 1 + index of this hub segment's bound slots, 0: none
     const i64 pu = g.price[u];
+    if (seg1) {
+        // no residual arc of the segment has a key above the bound: with bound <= price[u] none is
+        // admissible, and the bound stands in for the segment's relabel candidate
+        i64 b = g.seg_scan[seg1 - 1];
+        const i64 b0 = g.seg_add[0][seg1 - 1], b1 = g.seg_add[1][seg1 - 1];
+        b = b > b0 ? b : b0;
+        b = b > b1 ? b : b1;
+        if (b <= pu) {
+            if (lane == 0 && b > kNegInf) amax64(&g.cand[u], b);
+            return;
+        }
+    }
     i64 e0 = __hip_atomic_load(&g.excess[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     e0 = __shfl(e0, 0);
     if (lane == 0) t.c[kTallyVisits]++;
@@ -251,9 +299,13 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
         load9(g.head, a0, lim8, at, limt, hd);
         load9(g.cost, a0, lim8, at, limt, cs);
         t.c[kTallyScans] += count9(a0, lim8, at, limt);
-        i64 key[9], want = 0;
+        i64 key[9], ph[9], want = 0;
+        bool live[9];
 #pragma unroll
-        for (int j = 0; j < 9; ++j) key[j] = cp[j] > 0 ? g.price[hd[j]] - (i64)cs[j] * S : kNegInf;
+        for (int j = 0; j < 9; ++j) live[j] = cp[j] > 0;
+        gather9(hd, live, ph, (i64)0, [&](int v) { return g.price[v]; });
+#pragma unroll
+        for (int j = 0; j < 9; ++j) key[j] = live[j] ? ph[j] - (i64)cs[j] * S : kNegInf;
 #pragma unroll
         for (int j = 0; j < 9; ++j) if (key[j] > pu) want += cp[j];
         if (__ballot(want > 0)) {
@@ -283,9 +335,10 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
                 }
                 int rv[9], cr[9], hub[9];
 #pragma unroll
-                for (int j = 0; j < 9; ++j) { rv[j] = d[j] > 0 ? g.rev[arc9(a0, at, j)] : 0; hub[j] = d[j] > 0 ? g.hub_of[hd[j]] : -1; }
-#pragma unroll
-                for (int j = 0; j < 9; ++j) cr[j] = d[j] > 0 ? g.cap[rv[j]] : 0;
+                for (int j = 0; j < 9; ++j) {  // rcap mirrors cap[rev]: no dependent load for the reverse capacity
+                    const bool on = d[j] > 0;
+                    rv[j] = on ? g.rev[arc9(a0, at, j)] : 0; hub[j] = on ? g.hub_of[hd[j]] : -1; cr[j] = on ? g.rcap[arc9(a0, at, j)] : 0;
+                }
 #pragma unroll
                 for (int j = 0; j < 9; ++j) {
                     if (d[j] > 0) {
@@ -293,7 +346,7 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
                         const int na = cp[j] - d[j], nr = cr[j] + d[j];
                         g.cap[a] = na; g.cap[rv[j]] = nr; g.rcap[a] = nr; g.rcap[rv[j]] = na;
                         const i64 kr = pu + (i64)cs[j] * S;  // key of the new residual arc (v,u)
-                        if (hub[j] >= 0) { lds_add(&hb.add[hub[j]], (i64)d[j]); lds_max(&hb.ext[hub[j]], kr); }
+                        if (hub[j] >= 0) { lds_add(&hb.add[hub[j]], (i64)d[j]); lds_max(&hb.ext[hub[j]], kr); seg_note(g, hub[j], rv[j], kr, par); }
                         else { aadd64(&g.excess[hd[j]], (i64)d[j]); amax64(&g.cand[hd[j]], kr); }
                         cp[j] = na;
                         t.c[kTallyPushes]++;
@@ -312,6 +365,12 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
     }
     best = wave_max(best);
     if (lane == 0) {
+        if (seg1 && !incomplete) {
+            // every arc of the segment was looked at: the bound is exact again; keys noted during
+            // earlier rounds of the other parity are covered by it (this round's notes are not)
+            g.seg_scan[seg1 - 1] = best;
+            g.seg_add[par ^ 1][seg1 - 1] = kNegInf;
+        }
         if (incomplete) best = kInf;  // arcs not looked at: no relabel this round
         if (best > kNegInf) amax64(&g.cand[u], best);
         if (solo && e != e0) aadd64(&g.excess[u], e - e0);
@@ -341,9 +400,9 @@ __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
     Tally t;
     for (unsigned i = wave; i < nseg; i += nwaves) {
         const int4 it = segl[i];
-        push_item(g, hb, it, S, mix32((unsigned)it.x, salt) >> 16, t);
+        push_item(g, hb, it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t);
     }
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, hb, lowl[i], S, t);
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, hb, lowl[i], S, k & 1, t);
     hub_flush_push(g, hb);
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyRounds]++;
     tally_flush<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds>(g, t);
@@ -393,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
             const i64 nc = act[i] ? kNegInf : kInf;
             if (v[i] < g.n && c[i] != nc) g.cand[v[i]] = nc;
         }
-        block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app);
+        block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app, &g);
     }
     tally_flush<kTallyRelabels>(g, t);
 }
@@ -405,6 +464,10 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
 __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) {
     Ctrl *ct = g.ctrl;
     if (!ct->sat_on) return;
+    // capacities change wholesale below: the hub segment bounds start over
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n_hub_segs; i += gridDim.x * kBlock) {
+        g.seg_scan[i] = kInf; g.seg_add[0][i] = kNegInf; g.seg_add[1][i] = kNegInf;
+    }
     const i64 eps = ct->eps, S = g.scale;
     Tally t;
     __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
@@ -481,7 +544,11 @@ __device__ __forceinline__ void waveq_flush_one(T *q, unsigned &n, unsigned *cnt
 // Distances are lowered by atomics during the sweep, so pre-checks read them past the
 // (non-coherent) vector L1.
 __device__ __forceinline__ i64 ld_dist(const DevGraph &g, int u) {
-    return __hip_atomic_load(&g.dist[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return dist_of(__hip_atomic_load(&g.dist[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ i64 arc_len(i64 rc, int sh) {
+    i64 l = (rc >> sh) + 1;
+    return l < 0 ? 0 : (l > kLenMax ? kLenMax : l);
 }
 
 // Commit up to NJ tentative distances per lane (nd[j] == kDistInf: none) and queue the
@@ -503,24 +570,26 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
         old[j] = kNegInf;
         if (nd[j] < kDistInf) {
             if (hub[j] >= 0) lds_min(&hub_min[hub[j]], nd[j]);
-            else old[j] = amin64(&g.dist[hd[j]], nd[j]);
+            else old[j] = amin64(&g.dist[hd[j]], dist_pack(nd[j], stamp));
         }
     }
-    unsigned st[NJ];
+    bool first[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        st[j] = stamp;
-        if (nd[j] < old[j]) {  // improved (old stays -inf for "no candidate" and for hubs)
+        // improved: the stored distance was larger (old stays -inf for "no candidate" and hubs);
+        // first: nobody lowered it during this sweep yet, so this lane queues the vertex
+        const bool improved = old[j] != kNegInf && nd[j] < dist_of(old[j]);
+        first[j] = improved && (unsigned)(old[j] & 0xFFFF) != stamp;
+        if (improved) {
             t.c[kTallyGuRelax]++;
             if (nd[j] > wmax) wmax = nd[j];
-            st[j] = axchg32(&g.fstamp[hd[j]], stamp);
         }
     }
     int cls[NJ];
     unsigned r0[NJ], r1[NJ], nl = 0, ns = 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {  // first improver in this iteration queues the vertex
-        const bool enq = st[j] != stamp;
+        const bool enq = first[j];
         cls[j] = enq ? (int)g.cls[hd[j]] : -1;
         r0[j] = enq ? g.row[hd[j]] : 0;
         r1[j] = enq ? g.row[hd[j] + 1] : 0;
@@ -591,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
     int4 *dseg = g.fr_seg[dst];
     const i64 S = g.scale;
     const int sh = ct->eps_shift;
-    const unsigned stamp = ct->gu_stamp_base + (unsigned)k + 1u;
+    const unsigned stamp = (ct->gu_stamp_base + (unsigned)k) % 65535u + 1u;  // 16 bits, never 0
     const unsigned rot = mix32(ct->epoch, stamp);
     const int lane = lane_id();
     const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -605,7 +674,7 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
         const int v = it.x;
         const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
         const bool solo = it.w & 1;
-        const i64 dv = g.dist[v], pv = g.price[v];
+        const i64 dv = dist_of(g.dist[v]), pv = g.price[v];
         for (unsigned h = r0; h < r1; h += kStep) {
             const unsigned a0 = h + lane * 8, lim8 = min(r1, h + 512), at = h + 512 + lane, limt = min(r1, h + kStep);
             int rc9[9], hd[9], cs[9];
@@ -627,20 +696,19 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
             }
             i64 pu[9], du[9], nd[9];
             int hub[9];
+            bool live[9];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const bool ok = rc9[j] > 0;
-                pu[j] = ok ? g.price[hd[j]] : 0;
-                du[j] = ok ? ld_dist(g, hd[j]) : 0;
-                hub[j] = ok ? g.hub_of[hd[j]] : -1;
-            }
+            for (int j = 0; j < 9; ++j) live[j] = rc9[j] > 0;
+            gather9(hd, live, pu, (i64)0, [&](int v) { return g.price[v]; });
+            gather9(hd, live, du, (i64)0, [&](int v) { return ld_dist(g, v); });
+            gather9(hd, live, hub, -1, [&](int v) { return g.hub_of[v]; });
+#pragma unroll
+            for (int j = 0; j < 9; ++j) if (!live[j]) hub[j] = -1;
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
                 nd[j] = kDistInf;
                 if (rc9[j] > 0) {
-                    const i64 rc = -(i64)cs[j] * S + pu[j] - pv;
-                    i64 l = (rc >> sh) + 1;
-                    if (l < 0) l = 0;
+                    const i64 l = arc_len(-(i64)cs[j] * S + pu[j] - pv, sh);
                     if (dv + l < du[j]) nd[j] = dv + l;
                 }
             }
@@ -661,7 +729,7 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
         const int2 it = have ? lowl[i] : make_int2(0, 0);
         const int v = it.x & 0x0FFFFFFF;
         const unsigned deg = have ? (unsigned)it.x >> 28 : 0u, r0 = (unsigned)it.y;
-        const i64 dv = have ? g.dist[v] : 0, pv = have ? g.price[v] : 0;
+        const i64 dv = have ? dist_of(g.dist[v]) : 0, pv = have ? g.price[v] : 0;
         int rc4[kLowMax], hd[kLowMax], cs[kLowMax], hub[kLowMax];
         i64 pu[kLowMax], du[kLowMax], nd[kLowMax];
 #pragma unroll
@@ -679,9 +747,7 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
         for (unsigned j = 0; j < kLowMax; ++j) {
             nd[j] = kDistInf;
             if (rc4[j] > 0) {
-                const i64 rc = -(i64)cs[j] * S + pu[j] - pv;
-                i64 l = (rc >> sh) + 1;
-                if (l < 0) l = 0;
+                const i64 l = arc_len(-(i64)cs[j] * S + pu[j] - pv, sh);
                 if (dv + l < du[j]) nd[j] = dv + l;
             }
         }
@@ -694,11 +760,11 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
             const int u = g.hub_vertex[i];
             const i64 nd = s_hmin[i];
             if (nd < ld_dist(g, u)) {
-                const i64 old = amin64(&g.dist[u], nd);
-                if (nd < old) {
+                const i64 old = amin64(&g.dist[u], dist_pack(nd, stamp));
+                if (nd < dist_of(old)) {
                     t.c[kTallyGuRelax]++;
                     if (nd > wmax) wmax = nd;
-                    if (axchg32(&g.fstamp[u], stamp) != stamp)  // hubs are always split vertices
+                    if ((unsigned)(old & 0xFFFF) != stamp)  // first to lower it in this sweep; hubs are always split vertices
                         append_split(dcnt, dseg, u, g.row[u], g.row[u + 1], rot ^ (unsigned)u);
                 }
             }
@@ -728,7 +794,7 @@ __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) {
             const bool in = v[i] < g.n;
             def[i] = in && g.excess[v[i]] < 0;
             cls[i] = in ? (int)g.cls[v[i]] : 0;
-            if (in) g.dist[v[i]] = def[i] ? 0 : kDistInf;
+            if (in) g.dist[v[i]] = def[i] ? 0 : dist_pack(kDistInf, 0);
         }
 #pragma unroll
         for (int i = 0; i < kVpt; ++i) { r0[i] = def[i] ? g.row[v[i]] : 0; r1[i] = def[i] ? g.row[v[i] + 1] : 0; }
@@ -746,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void k_gu_apply(DevGraph g) {
     const i64 dfar = ct->dmax + 1;
     bool bad = false;
     for (int v = blockIdx.x * kBlock + threadIdx.x; v < g.n; v += gridDim.x * kBlock) {
-        const i64 d = g.dist[v];
+        const i64 d = dist_of(g.dist[v]);
         if (d >= kDistInf && g.excess[v] > 0) bad = true;  // supply that reaches no deficit
         const i64 dd = d < kDistInf ? d : dfar;
         if (dd) g.price[v] -= eps * dd;
@@ -769,8 +835,10 @@ __global__ void k_begin(DevGraph g) {
             ct->dmax = 0;
             ct->tally_gus++;
             for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) ct->fr_cnt[i][j] = 0;
+            ct->gu_stamp_base = 0;
+        } else {
+            ct->gu_stamp_base += kGuIters;  // sweep stamps stay unique within one update
         }
-        ct->gu_stamp_base += 64;  // fresh dedupe stamps for this replay's iterations
     }
 }
 __global__ void k_mid(DevGraph g, int n_iters) {
@@ -780,6 +848,10 @@ __global__ void k_mid(DevGraph g, int n_iters) {
         const unsigned *c = ct->fr_cnt[n_iters % 3];
         if (c[kClsLow] + c[kClsSeg] == 0) {
             ct->gu_apply_on = 1; ct->gu_active = 0; ct->need_gu = 0; ct->rounds_on = 1;
+        } else if (ct->gu_stamp_base + 2u * kGuIters > 60000u) {
+            // the 16-bit sweep stamps are about to repeat: give this update up (leaving the prices
+            // alone is always valid) and go on with push/relabel rounds
+            ct->gu_active = 0; ct->need_gu = 0; ct->rounds_on = 1;
         }
     } else {
         ct->rounds_on = 1;
@@ -808,7 +880,9 @@ __global__ __launch_bounds__(kBlock) void k_reset(DevGraph g, const i64 *supply,
     for (int v = blockIdx.x * kBlock + threadIdx.x; v < g.n; v += gridDim.x * kBlock) {
         if (!keep_flow) { g.price[v] = 0; g.excess[v] = supply[v]; }
         g.cand[v] = kInf;
-        g.fstamp[v] = 0;
+    }
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n_hub_segs; i += gridDim.x * kBlock) {
+        g.seg_scan[i] = kInf; g.seg_add[0][i] = kNegInf; g.seg_add[1][i] = kNegInf;
     }
 }
 // rcap mirrors cap[rev]; excess from scratch for a kept flow: supply - outflow + inflow,
