@@ -343,8 +343,13 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     for (int i = 0; i < 2; ++i) { A(g.list_low[i], n) A(g.list_seg[i], (size_t)n + high_items) }
     for (int i = 0; i < 3; ++i) { A(g.fr_low[i], n) A(g.fr_seg[i], (size_t)n + high_items) }
     c->tally_slots = kGrid * (kBlock / 64);
+    A(g.dmax_part, (size_t)kGrid * (kBlock / 64))
     A(g.tally, (size_t)c->tally_slots * kTallyN) A(c->d_tally_out, kTallyN) A(g.ctrl, 1)
     if (std::getenv("PSN_TRACE")) { A(g.dbg, kDbgCap) A(g.dbg_cnt, 1) }
+#ifdef PSN_STAMPS
+    A(g.stamps, (size_t)kGrid * (kBlock / 64) * 16)
+    HIPCHK(c, hipMemset(g.stamps, 0, (size_t)kGrid * (kBlock / 64) * 16 * sizeof(unsigned long long)));
+#endif
 #undef A
     c->d_head = d_head; c->d_rev = d_rev;
     g.row = d_row; g.head = d_head; g.cost = c->d_cost; g.rev = d_rev; g.tail = d_tail; g.ocap = c->d_ocap; g.cls = d_cls;
@@ -788,6 +793,14 @@ int psn_debug_trace(psn_ctx *c, int32_t *out4, int64_t max_records, int64_t *cou
     *count = n;
     return PSN_OK;
 }
+
+#ifdef PSN_STAMPS
+int psn_debug_stamps(psn_ctx *c, unsigned long long *out) {  // kGrid * 4 waves * 16 values
+    if (!c || !out || !c->g.stamps) return PSN_EINVAL;
+    HIPCHK(c, hipMemcpy(out, c->g.stamps, (size_t)kGrid * (kBlock / 64) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PSN_OK;
+}
+#endif
 
 int psn_kernel_times(psn_ctx *c, double *ms, uint64_t *calls) {
     if (!c || !ms || !calls) return fail(c, PSN_EINVAL, "null argument");

@@ -203,13 +203,16 @@ __device__ __forceinline__ unsigned count9(unsigned a0, unsigned lim8, unsigned 
 // arcs and copies the value along; the tail arc (slot 8) is fetched on its own.
 template <typename T, typename F>
 __device__ __forceinline__ void gather9(const int (&hd)[9], const bool (&need)[9], T (&out)[9], T dflt, F load) {
-    bool have[9];
+    bool have[9], reuse[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-        const bool reuse = j > 0 && j < 8 && have[j > 0 ? j - 1 : 0] && hd[j] == hd[j > 0 ? j - 1 : 0];
-        out[j] = reuse ? out[j > 0 ? j - 1 : 0] : (need[j] ? load(hd[j]) : dflt);
-        have[j] = reuse || need[j];
+        reuse[j] = j > 0 && j < 8 && have[j > 0 ? j - 1 : 0] && hd[j] == hd[j > 0 ? j - 1 : 0];
+        have[j] = reuse[j] || need[j];
     }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) out[j] = (need[j] && !reuse[j]) ? load(hd[j]) : dflt;  // all loads in flight together
+#pragma unroll
+    for (int j = 1; j < 8; ++j) if (reuse[j]) out[j] = out[j - 1];
 }
 
 // A push over (u,v) makes the reverse arc r = (v,u) residual; if v is a hub, the bound of the
@@ -519,6 +522,22 @@ __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) {
     tally_flush<kTallySat>(g, t);
 }
 
+#ifdef PSN_STAMPS
+// Diagnostic build only: cycle stamps per wave of the global-update sweep (tools/stamps_report.py).
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(var) const unsigned long long var = stamp_now()
+#define STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, a, b)
+#endif
+
 // ------------------------------------------------------- global price update (K3)
 // Distances (in units of eps) to the nearest deficit over reversed residual arcs with
 // length floor(rc/eps)+1 >= 0, by frontier relaxation to a fixed point; then
@@ -541,11 +560,12 @@ __device__ __forceinline__ void waveq_flush_one(T *q, unsigned &n, unsigned *cnt
     n = 0;
 }
 
-// Distances are lowered by atomics during the sweep, so pre-checks read them past the
-// (non-coherent) vector L1.
-__device__ __forceinline__ i64 ld_dist(const DevGraph &g, int u) {
-    return dist_of(__hip_atomic_load(&g.dist[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
+// Distance pre-checks use plain loads.  The vector L1 is not coherent with the atomics that
+// lower distances during a sweep, but it starts every kernel empty and distances only go down
+// within one update, so a cached value can only be too large: the check then lets a
+// candidate through to the atomic min, which decides.  (Agent-scope atomic loads would be
+// fresher, but the compiler waits for each of them separately: nine serial round trips per step.)
+__device__ __forceinline__ i64 ld_dist(const DevGraph &g, int u) { return dist_of(g.dist[u]); }
 __device__ __forceinline__ i64 arc_len(i64 rc, int sh) {
     i64 l = (rc >> sh) + 1;
     return l < 0 ? 0 : (l > kLenMax ? kLenMax : l);
@@ -634,7 +654,7 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
     for (int j = 0; j < NJ; ++j) if (cls[j] == kClsHigh) append_split(dcnt, dseg, hd[j], r0[j], r1[j], rot ^ (unsigned)hd[j]);
 }
 
-__global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
+__global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_on) return;
     const int src = k % 3, dst = (k + 1) % 3, clr = (k + 2) % 3;
@@ -669,13 +689,28 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
     i64 wmax = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyGuIters]++;
     const int4 *segl = g.fr_seg[src];
+#ifdef PSN_STAMPS
+    unsigned long long acc_item = 0, acc_arcs = 0, acc_gather = 0, acc_commit = 0, n_steps = 0, n_items = 0;
+#endif
+    STAMP(ts_begin);
+#ifdef PSN_STAMPS
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     for (unsigned i = wave; i < nseg; i += nwaves) {
+        STAMP(ts_i0);
         const int4 it = segl[i];
         const int v = it.x;
         const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
         const bool solo = it.w & 1;
         const i64 dv = dist_of(g.dist[v]), pv = g.price[v];
+#ifdef PSN_STAMPS
+        asm volatile("" ::"v"(dv), "v"(pv), "v"(r0));  // the item, its distance and price are here
+        ++n_items;
+#endif
+        STAMP(ts_i1);
+        STAMP_ADD(acc_item, ts_i0, ts_i1);
         for (unsigned h = r0; h < r1; h += kStep) {
+            STAMP(ts_s0);
             const unsigned a0 = h + lane * 8, lim8 = min(r1, h + 512), at = h + 512 + lane, limt = min(r1, h + kStep);
             int rc9[9], hd[9], cs[9];
             load9(g.rcap, a0, lim8, at, limt, rc9);
@@ -694,6 +729,13 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
                     for (int j = 0; j < 9; ++j) { hd[j] = 0; cs[j] = 0; }
                 }
             }
+#ifdef PSN_STAMPS
+#pragma unroll
+            for (int j = 0; j < 9; ++j) asm volatile("" ::"v"(rc9[j]), "v"(hd[j]), "v"(cs[j]));
+            ++n_steps;
+#endif
+            STAMP(ts_s1);
+            STAMP_ADD(acc_arcs, ts_s0, ts_s1);
             i64 pu[9], du[9], nd[9];
             int hub[9];
             bool live[9];
@@ -719,9 +761,18 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
                     nd[j - 1] = kDistInf;
                 }
             }
+#ifdef PSN_STAMPS
+#pragma unroll
+            for (int j = 0; j < 9; ++j) asm volatile("" ::"v"(nd[j]), "v"(hub[j]));
+#endif
+            STAMP(ts_s2);
+            STAMP_ADD(acc_gather, ts_s1, ts_s2);
             gu_commit_batch<9>(g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
+            STAMP(ts_s3);
+            STAMP_ADD(acc_commit, ts_s2, ts_s3);
         }
     }
+    STAMP(ts_wave_items);
     const int2 *lowl = g.fr_low[src];
     const unsigned nlow_round = (nlow + 63) & ~63u;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow_round; i += gridDim.x * kBlock) {
@@ -753,13 +804,17 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
         }
         gu_commit_batch<(int)kLowMax>(g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
     }
+    STAMP(ts_lane_items);
     __syncthreads();  // hub minima of the whole workgroup are in LDS
+    STAMP(ts_barrier);
     for (int base = 0; base < g.nhubs; base += kBlock) {
         const int i = base + (int)threadIdx.x;
         if (i < g.nhubs && s_hmin[i] < kDistInf) {
             const int u = g.hub_vertex[i];
             const i64 nd = s_hmin[i];
-            if (nd < ld_dist(g, u)) {
+            // one check per hub and workgroup, against a fresh value (most workgroups arrive after
+            // the first few have lowered the hub's distance and can skip the same-address atomic)
+            if (nd < dist_of(__hip_atomic_load(&g.dist[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 const i64 old = amin64(&g.dist[u], dist_pack(nd, stamp));
                 if (nd < dist_of(old)) {
                     t.c[kTallyGuRelax]++;
@@ -770,11 +825,27 @@ __global__ __launch_bounds__(kBlock) void k_gu_expand(DevGraph g, int k) {
             }
         }
     }
+    STAMP(ts_hubs);
     waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
     waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);
+    // Largest distance handed out: kept per wave slot (no shared counter: thousands of waves
+    // raising one word serialise at the memory side); k_gu_apply folds the slots.
     wmax = wave_max(wmax);
-    if (lane == 0 && wmax > ct->dmax) amax64(&ct->dmax, wmax);
+    if (lane == 0 && wmax > 0) {
+        i64 *slot = g.dmax_part + wave;
+        if (wmax > *slot) *slot = wmax;
+    }
     tally_flush<kTallyGuScans, kTallyGuRelax, kTallyGuIters>(g, t);
+#ifdef PSN_STAMPS
+    if (g.stamps && nseg >= 9000 && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long ts_end = stamp_now();
+        unsigned long long *o = g.stamps + (size_t)wave * 16;
+        o[0] = ts_begin; o[1] = ts_wave_items; o[2] = ts_lane_items; o[3] = ts_barrier; o[4] = ts_hubs; o[5] = ts_end;
+        o[6] = n_items; o[7] = n_steps; o[8] = acc_item; o[9] = acc_arcs; o[10] = acc_gather; o[11] = acc_commit;
+        o[12] = rt_begin; o[13] = nseg; o[14] = (unsigned long long)k; o[15] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // dist = 0 at deficits (they seed frontier 0), "infinite" elsewhere.
@@ -783,6 +854,7 @@ __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) {
     if (!ct->gu_init_on) return;
     __shared__ unsigned s_app[2][kBlock / 64 + 1];
     const unsigned rot = mix32(ct->epoch, 0x5EEDu);
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < kGrid * (kBlock / 64); i += gridDim.x * kBlock) g.dmax_part[i] = 0;
     const int span = kBlock * kVpt;
     for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
         bool def[kVpt];
@@ -809,7 +881,15 @@ __global__ __launch_bounds__(kBlock) void k_gu_apply(DevGraph g) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_apply_on) return;
     const i64 eps = ct->eps;
-    const i64 dfar = ct->dmax + 1;
+    __shared__ i64 s_dmax[kBlock / 64];
+    i64 dm = 0;
+    for (int i = threadIdx.x; i < kGrid * (kBlock / 64); i += kBlock) { const i64 x = g.dmax_part[i]; dm = x > dm ? x : dm; }
+    dm = wave_max(dm);
+    if (lane_id() == 0) s_dmax[threadIdx.x >> 6] = dm;
+    __syncthreads();
+    dm = 0;
+    for (int i = 0; i < kBlock / 64; ++i) dm = s_dmax[i] > dm ? s_dmax[i] : dm;
+    const i64 dfar = dm + 1;
     bool bad = false;
     for (int v = blockIdx.x * kBlock + threadIdx.x; v < g.n; v += gridDim.x * kBlock) {
         const i64 d = dist_of(g.dist[v]);
@@ -832,7 +912,6 @@ __global__ void k_begin(DevGraph g) {
         if (!ct->gu_active) {
             ct->gu_active = 1;
             ct->gu_init_on = 1;
-            ct->dmax = 0;
             ct->tally_gus++;
             for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) ct->fr_cnt[i][j] = 0;
             ct->gu_stamp_base = 0;
