@@ -746,20 +746,23 @@ __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
             gather9(hd, live, hub, -1, [&](int v) { return g.hub_of[v]; });
 #pragma unroll
             for (int j = 0; j < 9; ++j) if (!live[j]) hub[j] = -1;
+            // Parallel arcs (a run of equal heads among a lane's 8 consecutive arcs) offer the same
+            // vertex; the arc length falls as the cost grows, so only the dearest live arc of a run
+            // matters: reduce the costs in 32 bits and do the 64-bit length arithmetic once per run,
+            // at its last arc.
+            int run_cost = INT32_MIN;
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
+                const bool cont = j > 0 && j < 8 && hd[j] == hd[j > 0 ? j - 1 : 0];
+                if (!cont) run_cost = INT32_MIN;
+                if (live[j] && cs[j] > run_cost) run_cost = cs[j];
+                const bool last = j >= 7 || hd[j < 8 ? j + 1 : 8] != hd[j];
                 nd[j] = kDistInf;
-                if (rc9[j] > 0) {
-                    const i64 l = arc_len(-(i64)cs[j] * S + pu[j] - pv, sh);
+                if (last && run_cost != INT32_MIN) {  // some arc of the run is live: pu/du/hub[j] hold the head's values
+                    const i64 l = arc_len(-(i64)run_cost * S + pu[j] - pv, sh);
                     if (dv + l < du[j]) nd[j] = dv + l;
                 }
-            }
-#pragma unroll
-            for (int j = 1; j < 8; ++j) {  // consecutive arcs to the same vertex: keep one candidate
-                if (nd[j] < kDistInf && nd[j - 1] < kDistInf && hd[j] == hd[j - 1]) {
-                    nd[j] = nd[j] < nd[j - 1] ? nd[j] : nd[j - 1];
-                    nd[j - 1] = kDistInf;
-                }
+                if (!(last && run_cost != INT32_MIN)) hub[j] = -1;
             }
 #ifdef PSN_STAMPS
 #pragma unroll
