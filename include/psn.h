@@ -111,7 +111,9 @@ int psn_upload_csr(psn_ctx *ctx, int32_t n, int64_t m2, const int64_t *row_off,
 /* CPU/memory arc-cost model on the device: prices every (task class e, machine m,
  * slot k) arc of the uploaded network in place (cost and capacity of the forward
  * arc, -cost / 0 on its reverse).  ec_arc_base[e] is the index of class e's first
- * slot arc; arcs of one class are laid out machine-major, slot-minor.  Stands in
+ * slot arc; arcs of one class are laid out machine-major, slot-minor, and their paired
+ * reverse arcs open the row of their machine (vertex 1 + m) class-major, slot-minor, as
+ * psn_build_network lays them out (anything else is PSN_EINVAL).  Stands in
  * for Firmament's cpu/mem cost model selected at
  * /root/reference/deploy/firmament-deployment.yaml:29 with the units of
  * /root/reference/pkg/k8sclient/podwatcher.go:382-386 (millicores, Kb). */

@@ -395,9 +395,10 @@ static int eval_costs_impl(psn_ctx *c, const psn_layout *lay, const int64_t *cap
         if (cap_mem[m] > (int64_t)4e15 || used_mem[m] > (int64_t)4e15 || cap_cpu[m] > (int64_t)4e15 || used_cpu[m] > (int64_t)4e15)
             return fail(c, PSN_EOVERFLOW, "machine quantity too large");
     }
+    if ((long long)1 + N + E > c->n) return fail(c, PSN_EINVAL, "layout does not match the uploaded network");
     HIPCHK(c, hipSetDevice(c->device));
-    i64 *d;  // one staging allocation: 4 machine arrays, 2 shape arrays, bases
-    const size_t cnt = 4 * (size_t)N + 3 * (size_t)E;
+    i64 *d;  // one staging allocation: 4 machine arrays, 2 shape arrays, bases, layout-check counter
+    const size_t cnt = 4 * (size_t)N + 3 * (size_t)E + 1;
     HIPCHK(c, hipMalloc((void **)&d, cnt * sizeof(i64)));
     std::vector<i64> h(cnt);
     std::copy(cap_cpu, cap_cpu + N, h.begin());
@@ -407,19 +408,27 @@ static int eval_costs_impl(psn_ctx *c, const psn_layout *lay, const int64_t *cap
     std::copy(req_cpu, req_cpu + E, h.begin() + 4 * (size_t)N);
     std::copy(req_mem, req_mem + E, h.begin() + 4 * (size_t)N + E);
     std::copy(ec_arc_base, ec_arc_base + E, h.begin() + 4 * (size_t)N + 2 * (size_t)E);
+    h[cnt - 1] = 0;
+    unsigned *d_bad = reinterpret_cast<unsigned *>(d + cnt - 1);
+    unsigned bad = 0;
     hipError_t e = hipMemcpyAsync(d, h.data(), cnt * sizeof(i64), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        const long long total = (long long)E * N;
-        const int grid = (int)std::min<long long>((total + kBlock - 1) / kBlock, 4096);
+        const long long total = 2LL * E * N;
+        const int grid = (int)std::min<long long>((total + kBlock - 1) / kBlock, 8192);
         hipLaunchKernelGGL(k_eval_costs, dim3(grid), dim3(kBlock), 0, c->stream, c->g, E, N, K, d, d + N, d + 2 * (size_t)N,
                            d + 3 * (size_t)N, d + 4 * (size_t)N, d + 4 * (size_t)N + E, d + 4 * (size_t)N + 2 * (size_t)E, c->d_cost,
                            c->d_ocap, keep_flow, (c->d_allow && c->allow_classes == E && c->allow_words == (N + 31) / 32) ? c->d_allow : nullptr,
-                           c->allow_words);
+                           c->allow_words, d_bad);
         e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_eval_costs", e);
+    if (bad) {
+        c->solved = false;
+        return fail(c, PSN_EINVAL, "machine rows do not start with the reverse slot arcs, class-major and slot-minor");
+    }
     if (!keep_flow) c->solved = false;  // the flow on re-priced arcs was reset
     return PSN_OK;
 }

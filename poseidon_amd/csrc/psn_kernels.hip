@@ -1004,33 +1004,94 @@ __global__ void k_tally_sum(DevGraph g, unsigned long long *out, int nslots) {
 }
 
 // ------------------------------------------------------------- arc-cost model (K1)
-// One thread per (task class e, machine m): K slot arcs, int64 arithmetic throughout.
+// Slot arcs (task class e -> machine m, slot k), int64 arithmetic throughout:
 //   fit  = min((cap_cpu-used_cpu)/req_cpu, (cap_mem-used_mem)/req_mem)
 //   cap  = k < fit;  cost = 1000*(used_cpu+(k+1)*req_cpu)/cap_cpu + 1000*(used_mem+(k+1)*req_mem)/cap_mem
+// The numerators grow linearly with k, so a thread divides twice per dimension (first
+// numerator, step) and carries quotient and remainder along its K slots.  Two kinds of
+// threads, both writing K consecutive entries next to their neighbours' (coalesced): one per
+// (e, m) for the forward arcs in the class rows, one per (m, e) for the paired reverse arcs,
+// which sit class-major, slot-minor at the start of the machine rows.  A kept flow is read
+// from the thread's own entries (forward: original minus residual capacity; reverse: its
+// residual capacity) and cut to the new capacity.
+struct SlotCosts {
+    i64 q, r, dq, dr, c;  // cost term of the current slot = q; next: q += dq + carry
+    __device__ SlotCosts(i64 used, i64 req, i64 cap) : c(cap) {
+        const i64 n0 = 1000 * (used + req), st = 1000 * req;
+        q = n0 / cap; r = n0 - q * cap;
+        dq = st / cap; dr = st - dq * cap;
+    }
+    __device__ void next() {
+        q += dq; r += dr;
+        if (r >= c) { r -= c; ++q; }
+    }
+};
 __global__ __launch_bounds__(kBlock) void k_eval_costs(DevGraph g, int E, int N, int K, const i64 *cap_cpu, const i64 *cap_mem,
                                                        const i64 *used_cpu, const i64 *used_mem, const i64 *req_cpu,
                                                        const i64 *req_mem, const i64 *ec_arc_base, int *mcost, int *mocap,
-                                                       int keep_flow, const unsigned *allow, int allow_words) {
-    const long long total = (long long)E * N;
-    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
-        const int e = (int)(i / N), m = (int)(i % N);
+                                                       int keep_flow, const unsigned *allow, int allow_words, unsigned *bad_layout) {
+    const long long groups = (long long)E * N;
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < 2 * groups; i += (long long)gridDim.x * kBlock) {
+        const bool fwd = i < groups;
+        const long long gi = fwd ? i : i - groups;
+        // forward threads run machine-fastest inside a class, reverse threads class-fastest inside a machine
+        const int e = fwd ? (int)(gi / N) : (int)(gi % E), m = fwd ? (int)(gi % N) : (int)(gi / E);
         const i64 cc = cap_cpu[m], cm = cap_mem[m], uc = used_cpu[m], um = used_mem[m];
         const i64 rc = req_cpu[e], rm = req_mem[e];
         const i64 fc = (cc - uc) / rc, fm = (cm - um) / rm;
         i64 fit = fc < fm ? fc : fm;
         if (allow && !((allow[(size_t)e * allow_words + (m >> 5)] >> (m & 31)) & 1u)) fit = 0;  // selector mismatch: no capacity
         const unsigned a0 = (unsigned)(ec_arc_base[e] + (i64)m * K);
+        const unsigned r0 = g.row[1 + m] + (unsigned)e * (unsigned)K;
+        if (!fwd && (r0 + (unsigned)K > g.row[2 + m] || (unsigned)g.rev[r0] != a0)) { aadd32(bad_layout, 1u); continue; }
+        SlotCosts sc(uc, rc, cc), sm(um, rm, cm);
+        const unsigned b0 = fwd ? a0 : r0;  // first of this thread's K entries
+        if (K == 8) {  // the usual shape: eight slots, written as two 16-byte stores per array
+            int c[8], cp[8], f[8], oc[8], old[8];
+            if (keep_flow) {
+                const int4u x0 = *reinterpret_cast<const int4u *>(g.cap + b0), x1 = *reinterpret_cast<const int4u *>(g.cap + b0 + 4);
+                old[0] = x0.x; old[1] = x0.y; old[2] = x0.z; old[3] = x0.w; old[4] = x1.x; old[5] = x1.y; old[6] = x1.z; old[7] = x1.w;
+                if (fwd) {
+                    const int4u y0 = *reinterpret_cast<const int4u *>(mocap + b0), y1 = *reinterpret_cast<const int4u *>(mocap + b0 + 4);
+                    oc[0] = y0.x; oc[1] = y0.y; oc[2] = y0.z; oc[3] = y0.w; oc[4] = y1.x; oc[5] = y1.y; oc[6] = y1.z; oc[7] = y1.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                c[k] = (int)(sc.q + sm.q);
+                cp[k] = k < fit ? 1 : 0;
+                f[k] = 0;  // flow kept on the arc, cut to the new capacity
+                if (keep_flow) { f[k] = fwd ? oc[k] - old[k] : old[k]; f[k] = f[k] < 0 ? 0 : (f[k] > cp[k] ? cp[k] : f[k]); }
+                sc.next(); sm.next();
+            }
+            int4u v0, v1;
+#define PUT8(dst, expr)                                                                          \
+            { int k = 0; v0.x = (expr); k = 1; v0.y = (expr); k = 2; v0.z = (expr); k = 3; v0.w = (expr);   \
+              k = 4; v1.x = (expr); k = 5; v1.y = (expr); k = 6; v1.z = (expr); k = 7; v1.w = (expr);       \
+              *reinterpret_cast<int4u *>((dst) + b0) = v0; *reinterpret_cast<int4u *>((dst) + b0 + 4) = v1; }
+            if (fwd) {
+                PUT8(mcost, c[k]) PUT8(mocap, cp[k]) PUT8(g.cap, cp[k] - f[k]) PUT8(g.rcap, f[k])
+            } else {
+                PUT8(mcost, -c[k]) PUT8(mocap, 0 * k) PUT8(g.cap, f[k]) PUT8(g.rcap, cp[k] - f[k])
+            }
+#undef PUT8
+            continue;
+        }
         for (int k = 0; k < K; ++k) {
-            const i64 c = (1000 * (uc + (k + 1) * rc)) / cc + (1000 * (um + (k + 1) * rm)) / cm;
+            const int c = (int)(sc.q + sm.q);
             const int cp = k < fit ? 1 : 0;
-            const unsigned a = a0 + k;
-            const int r = g.rev[a];
-            int f = 0;  // flow kept on the arc, cut to the new capacity
-            if (keep_flow) { f = mocap[a] - g.cap[a]; f = f < 0 ? 0 : (f > cp ? cp : f); }
-            mcost[a] = (int)c; mcost[r] = -(int)c;
-            mocap[a] = cp; mocap[r] = 0;
-            g.cap[a] = cp - f; g.cap[r] = f;
-            g.rcap[a] = f; g.rcap[r] = cp - f;
+            if (fwd) {
+                const unsigned a = a0 + k;
+                int f = 0;
+                if (keep_flow) { f = mocap[a] - g.cap[a]; f = f < 0 ? 0 : (f > cp ? cp : f); }
+                mcost[a] = c; mocap[a] = cp; g.cap[a] = cp - f; g.rcap[a] = f;
+            } else {
+                const unsigned r = r0 + k;
+                int f = 0;
+                if (keep_flow) { f = g.cap[r]; f = f < 0 ? 0 : (f > cp ? cp : f); }
+                mcost[r] = -c; mocap[r] = 0; g.cap[r] = f; g.rcap[r] = cp - f;
+            }
+            sc.next(); sm.next();
         }
     }
 }

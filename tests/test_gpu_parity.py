@@ -246,3 +246,21 @@ def test_batch_of_independent_networks_matches_oracle():
         batch.solve_batch([solvers[0], solvers[0]])
     for s in solvers:
         s.close()
+
+
+def test_cost_model_rejects_a_layout_it_cannot_price():
+    """psn_eval_costs pairs every class row with the machine rows; arc bases that do not line
+    up with the uploaded network are refused instead of pricing the wrong arcs."""
+    cl = pa.synth_cluster(0, 1)
+    net = pa.build_network(cl)
+    with pa.Solver() as sv:
+        sv.upload(net)
+        good = net.ec_arc_base.copy()
+        net.ec_arc_base = good - 8
+        with pytest.raises(_lib.PsnError) as e:
+            sv.eval_costs(cl, net)
+        assert e.value.code == _lib.PSN_EINVAL
+        net.ec_arc_base = good
+        sv.upload(net)
+        sv.eval_costs(cl, net)
+        assert sv.solve().total_cost == 587046
