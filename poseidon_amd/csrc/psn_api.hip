@@ -774,7 +774,7 @@ static int run_placements(psn_ctx *c, const psn_layout *lay) {
         c->place_count = P; c->slot_stride = P; c->slot_classes = E;
     }
     hipLaunchKernelGGL(k_fill_i32, dim3(256), dim3(kBlock), 0, c->stream, c->d_place, -1, (long long)P);
-    hipLaunchKernelGGL(k_placements, dim3(E), dim3(kBlock), 0, c->stream, c->g, N, E, K, 1 + N + E + J, c->d_slot_machine, P, c->d_place);
+    hipLaunchKernelGGL(k_placements, dim3(E), dim3(kPlaceBlock), 0, c->stream, c->g, N, E, K, 1 + N + E + J, c->d_slot_machine, P, c->d_place);
     HIPCHK(c, hipGetLastError());
     return PSN_OK;
 }

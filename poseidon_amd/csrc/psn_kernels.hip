@@ -1100,6 +1100,7 @@ __global__ __launch_bounds__(kBlock) void k_eval_costs(DevGraph g, int E, int N,
 // Tasks of one class are interchangeable, so the class's routed tasks (in arc order) are
 // matched to its units of outgoing flow (in arc order).  One workgroup per class:
 // pass 1 numbers the units of flow on slot arcs, pass 2 numbers the routed tasks.
+constexpr int kPlaceBlock = 1024;  // threads per class in k_placements
 __device__ __forceinline__ unsigned block_excl_scan(unsigned x, unsigned *lds, unsigned &total) {
     const int lane = lane_id(), w = threadIdx.x >> 6;
     unsigned incl = x;
@@ -1108,14 +1109,14 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned x, unsigned *lds, u
     if (lane == 63) lds[w] = incl;
     __syncthreads();
     unsigned off = 0, tot = 0;
-    for (int i = 0; i < kBlock / 64; ++i) { if (i < w) off += lds[i]; tot += lds[i]; }
+    for (int i = 0; i < kPlaceBlock / 64; ++i) { if (i < w) off += lds[i]; tot += lds[i]; }
     __syncthreads();
     total = tot;
     return off + incl - x;
 }
-__global__ __launch_bounds__(kBlock) void k_placements(DevGraph g, int N, int E, int K, int v_task0, int *slot_machine,
-                                                       int slot_stride, int *place) {
-    __shared__ unsigned lds[kBlock / 64];
+__global__ __launch_bounds__(kPlaceBlock) void k_placements(DevGraph g, int N, int E, int K, int v_task0, int *slot_machine,
+                                                            int slot_stride, int *place) {
+    __shared__ unsigned lds[kPlaceBlock / 64];
     const int e = blockIdx.x;
     if (e >= E) return;
     const int u = 1 + N + e;
@@ -1124,19 +1125,32 @@ __global__ __launch_bounds__(kBlock) void k_placements(DevGraph g, int N, int E,
     const unsigned t1 = r1 - nslot;  // [r0,t1): reverse arcs to tasks, [t1,r1): slot arcs
     int *sm = slot_machine + (size_t)e * slot_stride;
     unsigned run = 0;
-    for (unsigned b = t1; b < r1; b += kBlock) {
-        const unsigned a = b + threadIdx.x;
+    for (unsigned b = t1; b < r1; b += kPlaceBlock * 4) {  // four consecutive slot arcs per thread
+        const unsigned a0 = b + threadIdx.x * 4;
+        int fl[4] = {0, 0, 0, 0};
+        if (a0 + 3 < r1) {
+            const int4u oc = *reinterpret_cast<const int4u *>(g.ocap + a0), cp = *reinterpret_cast<const int4u *>(g.cap + a0);
+            fl[0] = oc.x - cp.x; fl[1] = oc.y - cp.y; fl[2] = oc.z - cp.z; fl[3] = oc.w - cp.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (a0 + j < r1) fl[j] = g.ocap[a0 + j] - g.cap[a0 + j];
+        }
         unsigned f = 0;
-        if (a < r1) { int fl = g.ocap[a] - g.cap[a]; f = fl > 0 ? (unsigned)fl : 0; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { fl[j] = fl[j] > 0 ? fl[j] : 0; f += (unsigned)fl[j]; }
         unsigned tot;
         unsigned pos = run + block_excl_scan(f, lds, tot);
-        for (unsigned j = 0; j < f; ++j) if (pos + j < (unsigned)slot_stride) sm[pos + j] = g.head[a] - 1;
+        if (f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                for (int x = 0; x < fl[j]; ++x, ++pos) if (pos < (unsigned)slot_stride) sm[pos] = g.head[a0 + j] - 1;
+        }
         run += tot;
     }
     __syncthreads();
     const unsigned units = run;
     run = 0;
-    for (unsigned b = r0; b < t1; b += kBlock) {
+    for (unsigned b = r0; b < t1; b += kPlaceBlock) {
         const unsigned a = b + threadIdx.x;
         unsigned f = 0;
         if (a < t1) f = g.cap[a] > 0 ? 1u : 0u;  // residual on the reverse arc == task routed here
