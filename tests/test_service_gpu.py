@@ -91,6 +91,26 @@ def test_schedule_rounds_cold_then_warm(cfg, seed):
                 assert machine_index(s.task_placement(u)) == where.get(u, -1)
 
 
+def test_churn_round_at_full_scale():
+    """The incremental configuration at the 10k-machine / 100k-pod size: one cold round, one churn
+    round applied in place and warm-started; both optima equal the oracle's from-scratch optimum."""
+    cl = synth.make_cluster(2, 1)
+    with pa.SchedulerService(device=0) as s:
+        uids = feed_cluster(s, cl)
+        deltas = s.Schedule()
+        st = s.stats()
+        assert st.total_cost == 56359449 and len(deltas) == st.tasks_placed
+        cl2, ch = synth.churn(cl, 2, 1, 1)
+        uids = apply_churn(s, cl2, ch, uids, int(uids.max()) + 1)
+        deltas = s.Schedule()
+        st = s.stats()
+        assert st.last_round_warm == 1 and st.rebuilds == 1
+        assert st.total_cost == oracle_cost(cl2)
+        assert st.patched_arcs > 0 and st.patched_arcs < 40_000  # only what changed crossed PCIe
+        new = set(int(u) for u in uids[ch.pods_replaced])
+        assert all(d.type == CT.PLACE for d in deltas if d.task_id in new)
+
+
 def test_warm_round_moves_few_tasks():
     """A warm round after 5 % churn must not reshuffle the cluster: deltas stay a small
     multiple of what changed."""
