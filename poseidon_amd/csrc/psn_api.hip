@@ -188,6 +188,9 @@ __global__ void k_max_violation(DevGraph g, i64 *out) {
 }
 
 constexpr int kScalarSlots = 40;
+#ifdef PSN_STAMPS
+constexpr size_t kStampWords = (size_t)65536 + (size_t)8 * 64 * 4096 * 2 + (size_t)8 * 64 * 2;
+#endif
 
 int ceil_log2(i64 x) {
     int s = 0;
@@ -347,8 +350,8 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     A(g.tally, (size_t)c->tally_slots * kTallyN) A(c->d_tally_out, kTallyN) A(g.ctrl, 1)
     if (std::getenv("PSN_TRACE")) { A(g.dbg, kDbgCap) A(g.dbg_cnt, 1) }
 #ifdef PSN_STAMPS
-    A(g.stamps, (size_t)kGrid * (kBlock / 64) * 16)
-    HIPCHK(c, hipMemset(g.stamps, 0, (size_t)kGrid * (kBlock / 64) * 16 * sizeof(unsigned long long)));
+    A(g.stamps, kStampWords)
+    HIPCHK(c, hipMemset(g.stamps, 0, kStampWords * sizeof(unsigned long long)));
 #endif
 #undef A
     c->d_head = d_head; c->d_rev = d_rev;
@@ -807,6 +810,11 @@ int psn_debug_trace(psn_ctx *c, int32_t *out4, int64_t max_records, int64_t *cou
 int psn_debug_stamps(psn_ctx *c, unsigned long long *out) {  // kGrid * 4 waves * 16 values
     if (!c || !out || !c->g.stamps) return PSN_EINVAL;
     HIPCHK(c, hipMemcpy(out, c->g.stamps, (size_t)kGrid * (kBlock / 64) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PSN_OK;
+}
+int psn_debug_spans(psn_ctx *c, unsigned long long *out) {  // kStampWords - 65536 values
+    if (!c || !out || !c->g.stamps) return PSN_EINVAL;
+    HIPCHK(c, hipMemcpy(out, c->g.stamps + 65536, (kStampWords - 65536) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PSN_OK;
 }
 #endif

@@ -73,7 +73,69 @@ __device__ __forceinline__ unsigned mix32(unsigned a, unsigned b) {
 // Per-wave work counters; folded into a per-wave slot (no atomics: wave w of block b owns
 // slot (b, w) in every launch, and launches on one stream are ordered).  A wave that
 // counted nothing skips the fold.
-struct Tally { unsigned long long c[kTallyN]; __device__ Tally() { for (int i = 0; i < kTallyN; ++i) c[i] = 0; } };
+#ifdef PSN_STAMPS
+// Diagnostic build only: cycle stamps per wave of the global-update sweep (tools/stamps_report.py).
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+// Per launch and wave: begin and end on the 100 MHz clock, for replays kSpanEpoch0 .. +8 only
+// (plain stores into the wave's own slots; the host takes min / max):
+// stamps[65536 + (((epoch - kSpanEpoch0) * 64 + slot) * 4096 + wave) * 2 ...]; work sizes at the
+// end of the buffer.
+constexpr unsigned kSpanEpoch0 = 40, kSpanEpochs = 8;
+__device__ __forceinline__ unsigned long long *span_slot(const DevGraph &g, unsigned slot) {
+    const unsigned ep = g.ctrl->epoch - kSpanEpoch0;
+    if (!g.stamps || ep >= kSpanEpochs || lane_id() != 0) return nullptr;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    return g.stamps + 65536 + (((size_t)ep * 64 + slot) * 4096 + wave) * 2;
+}
+__device__ __forceinline__ void span_begin(const DevGraph &g, unsigned slot, unsigned long long a, unsigned long long b) {
+    unsigned long long *o = span_slot(g, slot);
+    if (!o) return;
+    o[0] = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long *w = g.stamps + 65536 + (size_t)kSpanEpochs * 64 * 4096 * 2 + ((size_t)(g.ctrl->epoch - kSpanEpoch0) * 64 + slot) * 2;
+        w[0] = a; w[1] = b;
+    }
+}
+__device__ __forceinline__ void span_end(const DevGraph &g, unsigned slot) {
+    unsigned long long *o = span_slot(g, slot);
+    if (!o) return;
+    __builtin_amdgcn_s_waitcnt(0);
+    o[1] = __builtin_amdgcn_s_memrealtime();
+}
+#define SPAN_BEGIN(slot, a, b) span_begin(g, slot, a, b)
+#define SPAN_END(slot) span_end(g, slot)
+#define STAMP(var) const unsigned long long var = stamp_now()
+#define STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, a, b)
+#define SPAN_BEGIN(slot, a, b)
+#define SPAN_END(slot)
+#endif
+
+// Per-wave work counters.  The wave's slot in memory is read when the sweep starts
+// (tally_prefetch) and written back with the sums when it ends, so that the read-modify-write
+// does not add a memory round trip to the end of every wave.
+struct Tally {
+    unsigned long long c[kTallyN], base[kTallyN];
+    __device__ Tally() { for (int i = 0; i < kTallyN; ++i) { c[i] = 0; base[i] = 0; } }
+};
+__device__ __forceinline__ unsigned long long *tally_slot(const DevGraph &g) {
+    return g.tally + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kTallyN;
+}
+template <int... Idx>
+__device__ __forceinline__ void tally_prefetch(const DevGraph &g, Tally &t) {
+    if (lane_id() == 0) {
+        const unsigned long long *slot = tally_slot(g);
+        ((t.base[Idx] = slot[Idx]), ...);
+    }
+}
 template <int... Idx>
 __device__ __forceinline__ void tally_flush(const DevGraph &g, Tally &t) {
     unsigned long long any = 0;
@@ -81,8 +143,8 @@ __device__ __forceinline__ void tally_flush(const DevGraph &g, Tally &t) {
     if (!__ballot(any != 0)) return;
     ((t.c[Idx] = wave_sum_u64(t.c[Idx])), ...);
     if (lane_id() == 0) {
-        unsigned long long *slot = g.tally + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kTallyN;
-        ((slot[Idx] += t.c[Idx]), ...);
+        unsigned long long *slot = tally_slot(g);
+        ((slot[Idx] = t.base[Idx] + t.c[Idx]), ...);
     }
 }
 
@@ -391,6 +453,7 @@ __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
         const unsigned i = aadd32(g.dbg_cnt, 1u);
         if (i < kDbgCap) g.dbg[i] = make_int4(1, k, (int)nlow, (int)nseg);
     }
+    SPAN_BEGIN(16u + 2u * (unsigned)k, nlow, nseg);
     __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
     const HubAcc hb{s_add, s_max};
     hub_init(hb, kNegInf);
@@ -401,6 +464,7 @@ __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
     const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
+    tally_prefetch<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds>(g, t);
     for (unsigned i = wave; i < nseg; i += nwaves) {
         const int4 it = segl[i];
         push_item(g, hb, it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t);
@@ -409,6 +473,7 @@ __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
     hub_flush_push(g, hb);
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyRounds]++;
     tally_flush<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds>(g, t);
+    SPAN_END(16u + 2u * (unsigned)k);
 }
 
 // Relabel (optional) + rebuild of the active lists for the next round: one sweep over
@@ -425,7 +490,9 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
     }
     const i64 eps = ct->eps;
     const unsigned rot = mix32(ct->epoch, (unsigned)k);
+    SPAN_BEGIN(do_relabel ? 17u + 2u * (unsigned)k : 15u, (unsigned long long)do_relabel, 0);
     Tally t;
+    tally_prefetch<kTallyRelabels>(g, t);
     __shared__ unsigned s_app[2][kBlock / 64 + 1];
     const int span = kBlock * kVpt;
     for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
@@ -458,6 +525,7 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
         block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app, &g);
     }
     tally_flush<kTallyRelabels>(g, t);
+    SPAN_END(do_relabel ? 17u + 2u * (unsigned)k : 15u);
 }
 
 // ------------------------------------------------------------- per-phase saturation
@@ -473,6 +541,7 @@ __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) {
     }
     const i64 eps = ct->eps, S = g.scale;
     Tally t;
+    tally_prefetch<kTallySat>(g, t);
     __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
     const HubAcc hb{s_add, s_max};
     hub_init(hb, kNegInf);
@@ -522,21 +591,6 @@ __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) {
     tally_flush<kTallySat>(g, t);
 }
 
-#ifdef PSN_STAMPS
-// Diagnostic build only: cycle stamps per wave of the global-update sweep (tools/stamps_report.py).
-__device__ __forceinline__ unsigned long long stamp_now() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define STAMP(var) const unsigned long long var = stamp_now()
-#define STAMP_ADD(acc, a, b) acc += (b) - (a)
-#else
-#define STAMP(var)
-#define STAMP_ADD(acc, a, b)
-#endif
 
 // ------------------------------------------------------- global price update (K3)
 // Distances (in units of eps) to the nearest deficit over reversed residual arcs with
@@ -686,6 +740,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
     const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
+    tally_prefetch<kTallyGuScans, kTallyGuRelax, kTallyGuIters>(g, t);
     i64 wmax = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyGuIters]++;
     const int4 *segl = g.fr_seg[src];
