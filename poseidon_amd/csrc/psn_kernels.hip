@@ -87,6 +87,10 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 // stamps[65536 + (((epoch - kSpanEpoch0) * 64 + slot) * 4096 + wave) * 2 ...]; work sizes at the
 // end of the buffer.
 constexpr unsigned kSpanEpoch0 = 40, kSpanEpochs = 8;
+#ifndef PSN_STAMP_EXPAND_MIN
+#define PSN_STAMP_EXPAND_MIN 9000u  // per-wave records of the expand sweep; above any frontier: the push sweep records instead
+#endif
+constexpr unsigned kStampExpandMin = PSN_STAMP_EXPAND_MIN;
 __device__ __forceinline__ unsigned long long *span_slot(const DevGraph &g, unsigned slot) {
     const unsigned ep = g.ctrl->epoch - kSpanEpoch0;
     if (!g.stamps || ep >= kSpanEpochs || lane_id() != 0) return nullptr;
@@ -230,13 +234,19 @@ __device__ __forceinline__ void excess_add(const DevGraph &g, const HubAcc &hb, 
     const int h = g.hub_of[v];
     if (h >= 0) lds_add(&hb.add[h], d); else aadd64(&g.excess[v], d);
 }
+// The vertex of hub slot threadIdx.x (kMaxHubs <= kBlock), fetched when a sweep starts so that
+// the flush at its end does not wait for a lookup.
+static_assert(kMaxHubs <= kBlock, "one thread per hub slot");
+__device__ __forceinline__ int hub_vertex_of_thread(const DevGraph &g) {
+    return (int)threadIdx.x < g.nhubs ? g.hub_vertex[threadIdx.x] : -1;
+}
 // end of a push/saturate kernel: one atomic per hub touched by this workgroup
-__device__ __forceinline__ void hub_flush_push(const DevGraph &g, const HubAcc &hb) {
+__device__ __forceinline__ void hub_flush_push(const DevGraph &g, const HubAcc &hb, int my_hub_vertex) {
     __syncthreads();
-    for (int i = threadIdx.x; i < g.nhubs; i += kBlock) {
-        const int v = g.hub_vertex[i];
-        if (hb.add[i]) aadd64(&g.excess[v], hb.add[i]);
-        if (hb.ext[i] > kNegInf) amax64(&g.cand[v], hb.ext[i]);
+    if (my_hub_vertex >= 0) {
+        const int i = threadIdx.x;
+        if (hb.add[i]) aadd64(&g.excess[my_hub_vertex], hb.add[i]);
+        if (hb.ext[i] > kNegInf) amax64(&g.cand[my_hub_vertex], hb.ext[i]);
     }
 }
 
@@ -328,8 +338,17 @@ __device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, in
 // several items has its waves claim what they want to push from excess[u] and hand back
 // what was not granted.  `rot` permutes which lane owns which arcs, so that the prefix
 // order (= who gets the excess first) changes from round to round.
-__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int4 it, i64 S, unsigned rot, int par, Tally &t) {
+#ifdef PSN_STAMPS
+struct PushStamps { unsigned long long pre = 0, arcs = 0, price = 0, push = 0, tail = 0, n = 0; };
+#define PS_ARG , PushStamps &ps
+#define PS_PASS , ps
+#else
+#define PS_ARG
+#define PS_PASS
+#endif
+__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int4 it, i64 S, unsigned rot, int par, Tally &t PS_ARG) {
     const int lane = lane_id();
+    STAMP(tp0);
     const int u = it.x;
     const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
     const bool solo = it.w & 1;
@@ -357,13 +376,25 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
     i64 e = e0, best = kNegInf;
     bool incomplete = false;
     const unsigned plane = (unsigned)(lane + rot) & 63u;
+    STAMP(tp1);
+    STAMP_ADD(ps.pre, tp0, tp1);
+#ifdef PSN_STAMPS
+    ps.n++;
+#endif
     for (unsigned h = r0; h < r1; h += kStep) {
+        STAMP(ta0);
         const unsigned a0 = h + plane * 8, lim8 = min(r1, h + 512), at = h + 512 + plane, limt = min(r1, h + kStep);
         int cp[9], hd[9], cs[9];
         load9(g.cap, a0, lim8, at, limt, cp);
         load9(g.head, a0, lim8, at, limt, hd);
         load9(g.cost, a0, lim8, at, limt, cs);
         t.c[kTallyScans] += count9(a0, lim8, at, limt);
+#ifdef PSN_STAMPS
+#pragma unroll
+        for (int j = 0; j < 9; ++j) asm volatile("" ::"v"(cp[j]), "v"(hd[j]), "v"(cs[j]));
+#endif
+        STAMP(ta1);
+        STAMP_ADD(ps.arcs, ta0, ta1);
         i64 key[9], ph[9], want = 0;
         bool live[9];
 #pragma unroll
@@ -373,6 +404,11 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
         for (int j = 0; j < 9; ++j) key[j] = live[j] ? ph[j] - (i64)cs[j] * S : kNegInf;
 #pragma unroll
         for (int j = 0; j < 9; ++j) if (key[j] > pu) want += cp[j];
+#ifdef PSN_STAMPS
+        asm volatile("" ::"v"(want));
+#endif
+        STAMP(ta2);
+        STAMP_ADD(ps.price, ta1, ta2);
         if (__ballot(want > 0)) {
             const i64 incl = wave_incl_scan(want);
             const i64 total = __shfl(incl, 63);
@@ -418,6 +454,8 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
                     }
                 }
             }
+            STAMP(ta3);
+            STAMP_ADD(ps.push, ta2, ta3);
             if (granted < total || (solo && e == 0)) {  // out of excess
 #pragma unroll
                 for (int j = 0; j < 9; ++j) if (cp[j] > 0 && key[j] > best) best = key[j];
@@ -428,6 +466,7 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
 #pragma unroll
         for (int j = 0; j < 9; ++j) if (cp[j] > 0 && key[j] > best) best = key[j];
     }
+    STAMP(tq0);
     best = wave_max(best);
     if (lane == 0) {
         if (seg1 && !incomplete) {
@@ -440,6 +479,8 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
         if (best > kNegInf) amax64(&g.cand[u], best);
         if (solo && e != e0) aadd64(&g.excess[u], e - e0);
     }
+    STAMP(tq1);
+    STAMP_ADD(ps.tail, tq0, tq1);
 }
 
 __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
@@ -465,14 +506,38 @@ __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
     tally_prefetch<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds>(g, t);
+    const int my_hub_vertex = hub_vertex_of_thread(g);
+#ifdef PSN_STAMPS
+    PushStamps ps;
+    unsigned long long acc_item = 0;
+#endif
+    STAMP(tk0);
     for (unsigned i = wave; i < nseg; i += nwaves) {
+        STAMP(ti0);
         const int4 it = segl[i];
-        push_item(g, hb, it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t);
+#ifdef PSN_STAMPS
+        asm volatile("" ::"v"(it.x), "v"(it.y), "v"(it.z), "v"(it.w));
+#endif
+        STAMP(ti1);
+        STAMP_ADD(acc_item, ti0, ti1);
+        push_item(g, hb, it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t PS_PASS);
     }
+    STAMP(tk1);
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, hb, lowl[i], S, k & 1, t);
-    hub_flush_push(g, hb);
+    STAMP(tk2);
+    hub_flush_push(g, hb, my_hub_vertex);
+    STAMP(tk3);
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyRounds]++;
     tally_flush<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds>(g, t);
+#ifdef PSN_STAMPS
+    if (g.stamps && nseg >= 200 && nseg < 3000 && nlow == 0 && lane_id() == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long tk4 = stamp_now();
+        unsigned long long *o = g.stamps + (size_t)wave * 16;
+        o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = tk4; o[5] = ps.n; o[6] = acc_item; o[7] = ps.pre; o[8] = ps.arcs;
+        o[9] = ps.price; o[10] = ps.push; o[11] = ps.tail; o[12] = nseg; o[13] = 777;
+    }
+#endif
     SPAN_END(16u + 2u * (unsigned)k);
 }
 
@@ -587,7 +652,7 @@ __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) {
             }
         }
     }
-    hub_flush_push(g, hb);
+    hub_flush_push(g, hb, hub_vertex_of_thread(g));
     tally_flush<kTallySat>(g, t);
 }
 
@@ -741,6 +806,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
     tally_prefetch<kTallyGuScans, kTallyGuRelax, kTallyGuIters>(g, t);
+    const int my_hub_vertex = hub_vertex_of_thread(g);
+    const unsigned my_hub_row0 = my_hub_vertex >= 0 ? g.row[my_hub_vertex] : 0u, my_hub_row1 = my_hub_vertex >= 0 ? g.row[my_hub_vertex + 1] : 0u;
     i64 wmax = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyGuIters]++;
     const int4 *segl = g.fr_seg[src];
@@ -865,21 +932,18 @@ __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
     STAMP(ts_lane_items);
     __syncthreads();  // hub minima of the whole workgroup are in LDS
     STAMP(ts_barrier);
-    for (int base = 0; base < g.nhubs; base += kBlock) {
-        const int i = base + (int)threadIdx.x;
-        if (i < g.nhubs && s_hmin[i] < kDistInf) {
-            const int u = g.hub_vertex[i];
-            const i64 nd = s_hmin[i];
-            // one check per hub and workgroup, against a fresh value (most workgroups arrive after
-            // the first few have lowered the hub's distance and can skip the same-address atomic)
-            if (nd < dist_of(__hip_atomic_load(&g.dist[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                const i64 old = amin64(&g.dist[u], dist_pack(nd, stamp));
-                if (nd < dist_of(old)) {
-                    t.c[kTallyGuRelax]++;
-                    if (nd > wmax) wmax = nd;
-                    if ((unsigned)(old & 0xFFFF) != stamp)  // first to lower it in this sweep; hubs are always split vertices
-                        append_split(dcnt, dseg, u, g.row[u], g.row[u + 1], rot ^ (unsigned)u);
-                }
+    if (my_hub_vertex >= 0 && s_hmin[threadIdx.x] < kDistInf) {
+        const int u = my_hub_vertex;
+        const i64 nd = s_hmin[threadIdx.x];
+        // one check per hub and workgroup, against a fresh value (most workgroups arrive after
+        // the first few have lowered the hub's distance and can skip the same-address atomic)
+        if (nd < dist_of(__hip_atomic_load(&g.dist[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            const i64 old = amin64(&g.dist[u], dist_pack(nd, stamp));
+            if (nd < dist_of(old)) {
+                t.c[kTallyGuRelax]++;
+                if (nd > wmax) wmax = nd;
+                if ((unsigned)(old & 0xFFFF) != stamp)  // first to lower it in this sweep; hubs are always split vertices
+                    append_split(dcnt, dseg, u, my_hub_row0, my_hub_row1, rot ^ (unsigned)u);
             }
         }
     }
@@ -895,7 +959,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
     }
     tally_flush<kTallyGuScans, kTallyGuRelax, kTallyGuIters>(g, t);
 #ifdef PSN_STAMPS
-    if (g.stamps && nseg >= 9000 && lane == 0) {
+    if (g.stamps && nseg >= kStampExpandMin && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long ts_end = stamp_now();
         unsigned long long *o = g.stamps + (size_t)wave * 16;

@@ -43,6 +43,18 @@ for ep in range(EP):
                 gaps_pr.append((b[ep, sr, 0] - b[ep, sp, 1]) / 100.0)
                 if k + 1 < 12 and valid[ep, sp + 2]:
                     gaps_rp.append((b[ep, sp + 2, 0] - b[ep, sr, 1]) / 100.0)
+for ep, k in ((7, 5), (7, 9), (4, 3)):
+    sp = 16 + 2 * k
+    if valid[ep, sp]:
+        lw = life[ep, sp] / 100.0
+        hs = has[ep, sp]
+        t0 = b[ep, sp, 0]
+        print(f"  epoch {ep} round {k}: {b[ep, sp, 3]} wave items; wave life histogram (us):",
+              " ".join(f"<{e}:{int(((lw < e) & (lw >= lo) & hs).sum())}" for lo, e in ((0, 1), (1, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 14), (14, 20), (20, 99))))
+        longw = np.where(hs & (lw >= 8))[0]
+        print("     waves living >= 8 us: count", len(longw), "indices", longw[:40], " their begins (us after first):", np.round((w[ep, sp, longw[:12], 0] - t0) / 100.0, 1))
+        idle = hs & (np.arange(W) >= b[ep, sp, 3])
+        print("     waves without an item: life mean %.2f us, begin (us after first) p50 %.1f max %.1f" % (lw[idle].mean(), np.percentile((w[ep, sp, idle, 0] - t0) / 100.0, 50), ((w[ep, sp, idle, 0] - t0) / 100.0).max()))
 push = np.array(push)
 print("push launches", len(push), " relabel launches", len(rel))
 for lo, hi in ((0, 64), (64, 1024), (1024, 4096), (4096, 1 << 30)):
