@@ -248,3 +248,29 @@ def test_node_selector_end_to_end():
         g, _ = exported_graph(s)
         rc, tc, _, _, _ = capi.cost_scaling(g)
         assert rc == 0 and tc == s.stats().total_cost
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_rpc_sequences_scheduled_on_the_gpu(seed):
+    """Random RPC bursts with a Schedule after each: the round's cost (warm or after a new layout)
+    equals the oracle's optimum of the cluster described from scratch, and no task sits on a machine
+    that left or that its selectors exclude."""
+    from svc_util import RpcModel, model_cost, random_rpcs, rpc_shapes
+    rng = np.random.default_rng(seed)
+    shapes, st = rpc_shapes(), RpcModel()
+    where = {}
+    with pa.SchedulerService(device=0, max_machines=8, max_tasks=64, max_jobs=4) as s:
+        warm = 0
+        for burst in range(14):
+            random_rpcs(s, rng, st, shapes, int(rng.integers(10, 80)))
+            deltas = s.Schedule()
+            stt = s.stats()
+            warm += stt.last_round_warm
+            assert stt.total_cost == model_cost(st.machines, st.tasks, shapes), (seed, burst)
+            for d in deltas:
+                assert d.task_id in st.tasks
+                where[d.task_id] = d.resource_id if d.type != CT.PREEMPT else ""
+            for u, (e, _) in st.tasks.items():
+                res = s.task_placement(u)
+                assert res == "" or res in st.machines
+        assert warm >= 5 and s.stats().rebuilds >= 2

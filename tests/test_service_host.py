@@ -160,3 +160,20 @@ def test_selectors_shape_the_admission_mask():
         rc, tc, _, _, _ = capi.cost_scaling(g)
         assert rc == 0 and tc >= synth.C_UNSCHED  # task 8 can go nowhere: it pays the unscheduled cost
         assert tc < 2 * synth.C_UNSCHED
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_rpc_sequences_keep_the_network_right(seed):
+    """Random interleavings of every mutating RPC; after each burst the optimum of the service's
+    network (solved by the oracle) equals the optimum of the same cluster described from scratch."""
+    from svc_util import RpcModel, model_cost, random_rpcs, rpc_shapes
+    rng = np.random.default_rng(seed)
+    shapes, st = rpc_shapes(), RpcModel()
+    with pa.SchedulerService(device=-1, max_machines=8, max_tasks=64, max_jobs=4) as s:
+        for burst in range(12):
+            random_rpcs(s, rng, st, shapes, int(rng.integers(20, 120)))
+            g, _ = exported_graph(s)
+            _check_structure(g)
+            rc, tc, _, _, _ = capi.cost_scaling(g)
+            assert rc == 0 and tc == model_cost(st.machines, st.tasks, shapes), (seed, burst)
+        assert s.stats().rebuilds >= 2  # the small initial capacities were outgrown on the way
