@@ -34,7 +34,6 @@ enum { kTallyScans = 0, kTallyPushes, kTallyRelabels, kTallyVisits, kTallyGuScan
 // stage is off, which is what lets a fixed hipGraph be replayed until `done`.
 struct Ctrl {
     i64 eps;
-    i64 dmax;
     int eps_shift, alpha_log2;
     int need_sat, need_gu, gu_active;
     int sat_on, gu_on, gu_init_on, gu_apply_on, rounds_on;
