@@ -395,20 +395,33 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
 #endif
         STAMP(ta1);
         STAMP_ADD(ps.arcs, ta0, ta1);
-        i64 key[9], ph[9], want = 0;
+        // Keys price[head] - cost * S are not kept per arc: what later steps need is which arcs are
+        // admissible (a bit mask), the largest key of all live arcs and the largest key among the
+        // live arcs that are not admissible.  If an admissible arc is still residual after the
+        // pushes, the vertex needs no relabel and any value above its price serves as candidate
+        // (the largest key of all does, and it also bounds the segment from above); otherwise the
+        // candidate is exactly the largest non-admissible key.
+        i64 ph[9], want = 0, kmax_all = kNegInf, kmax_rest = kNegInf;
+        unsigned adm = 0;
         bool live[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) live[j] = cp[j] > 0;
         gather9(hd, live, ph, (i64)0, [&](int v) { return g.price[v]; });
 #pragma unroll
-        for (int j = 0; j < 9; ++j) key[j] = live[j] ? ph[j] - (i64)cs[j] * S : kNegInf;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) if (key[j] > pu) want += cp[j];
+        for (int j = 0; j < 9; ++j) {
+            if (live[j]) {
+                const i64 key = ph[j] - (i64)cs[j] * S;
+                kmax_all = key > kmax_all ? key : kmax_all;
+                if (key > pu) { adm |= 1u << j; want += cp[j]; }
+                else kmax_rest = key > kmax_rest ? key : kmax_rest;
+            }
+        }
 #ifdef PSN_STAMPS
         asm volatile("" ::"v"(want));
 #endif
         STAMP(ta2);
         STAMP_ADD(ps.price, ta1, ta2);
+        bool stop = false;
         if (__ballot(want > 0)) {
             const i64 incl = wave_incl_scan(want);
             const i64 total = __shfl(incl, 63);
@@ -427,44 +440,53 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
             }
             i64 mine = granted - (incl - want);  // what this lane may push
             if (mine > 0) {
-                // amounts first, then every load of the batch before any dependent store
-                int d[9];
+                // two batches (slots 0-4, 5-8): amounts first, then every load of the batch before any
+                // dependent store
 #pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    d[j] = 0;
-                    if (key[j] > pu && mine > 0) { d[j] = (int)(mine < cp[j] ? mine : cp[j]); mine -= d[j]; }
-                }
-                int rv[9], cr[9], hub[9];
+                for (int b0 = 0; b0 < 9; b0 += 5) {
+                    constexpr int W = 5;
+                    int d[W], rv[W], cr[W], hub[W];
 #pragma unroll
-                for (int j = 0; j < 9; ++j) {  // rcap mirrors cap[rev]: no dependent load for the reverse capacity
-                    const bool on = d[j] > 0;
-                    rv[j] = on ? g.rev[arc9(a0, at, j)] : 0; hub[j] = on ? g.hub_of[hd[j]] : -1; cr[j] = on ? g.rcap[arc9(a0, at, j)] : 0;
-                }
+                    for (int x = 0; x < W; ++x) {
+                        const int j = b0 + x;
+                        d[x] = 0;
+                        if (j < 9 && ((adm >> j) & 1u) && mine > 0) { d[x] = (int)(mine < cp[j < 9 ? j : 0] ? mine : cp[j < 9 ? j : 0]); mine -= d[x]; }
+                    }
 #pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    if (d[j] > 0) {
-                        const unsigned a = arc9(a0, at, j);
-                        const int na = cp[j] - d[j], nr = cr[j] + d[j];
-                        g.cap[a] = na; g.cap[rv[j]] = nr; g.rcap[a] = nr; g.rcap[rv[j]] = na;
-                        const i64 kr = pu + (i64)cs[j] * S;  // key of the new residual arc (v,u)
-                        if (hub[j] >= 0) { lds_add(&hb.add[hub[j]], (i64)d[j]); lds_max(&hb.ext[hub[j]], kr); seg_note(g, hub[j], rv[j], kr, par); }
-                        else { aadd64(&g.excess[hd[j]], (i64)d[j]); amax64(&g.cand[hd[j]], kr); }
-                        cp[j] = na;
-                        t.c[kTallyPushes]++;
+                    for (int x = 0; x < W; ++x) {  // rcap mirrors cap[rev]: no dependent load for the reverse capacity
+                        const int j = b0 + x < 9 ? b0 + x : 8;
+                        const bool on = d[x] > 0;
+                        rv[x] = on ? g.rev[arc9(a0, at, j)] : 0; hub[x] = on ? g.hub_of[hd[j]] : -1; cr[x] = on ? g.rcap[arc9(a0, at, j)] : 0;
+                    }
+#pragma unroll
+                    for (int x = 0; x < W; ++x) {
+                        const int j = b0 + x < 9 ? b0 + x : 8;
+                        if (d[x] > 0) {
+                            const unsigned a = arc9(a0, at, j);
+                            const int na = cp[j] - d[x], nr = cr[x] + d[x];
+                            g.cap[a] = na; g.cap[rv[x]] = nr; g.rcap[a] = nr; g.rcap[rv[x]] = na;
+                            const i64 kr = pu + (i64)cs[j] * S;  // key of the new residual arc (v,u)
+                            if (hub[x] >= 0) { lds_add(&hb.add[hub[x]], (i64)d[x]); lds_max(&hb.ext[hub[x]], kr); seg_note(g, hub[x], rv[x], kr, par); }
+                            else { aadd64(&g.excess[hd[j]], (i64)d[x]); amax64(&g.cand[hd[j]], kr); }
+                            cp[j] = na;
+                            t.c[kTallyPushes]++;
+                        }
                     }
                 }
             }
             STAMP(ta3);
             STAMP_ADD(ps.push, ta2, ta3);
-            if (granted < total || (solo && e == 0)) {  // out of excess
-#pragma unroll
-                for (int j = 0; j < 9; ++j) if (cp[j] > 0 && key[j] > best) best = key[j];
-                if (h + kStep < r1) incomplete = true;
-                break;
-            }
+            stop = granted < total || (solo && e == 0);  // out of excess
         }
+        bool adm_left = false;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) if (cp[j] > 0 && key[j] > best) best = key[j];
+        for (int j = 0; j < 9; ++j) adm_left |= ((adm >> j) & 1u) && cp[j] > 0;
+        const i64 here = adm_left ? kmax_all : kmax_rest;
+        best = here > best ? here : best;
+        if (stop) {
+            if (h + kStep < r1) incomplete = true;
+            break;
+        }
     }
     STAMP(tq0);
     best = wave_max(best);
