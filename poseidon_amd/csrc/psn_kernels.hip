@@ -123,32 +123,23 @@ __device__ __forceinline__ void span_end(const DevGraph &g, unsigned slot) {
 #define SPAN_END(slot)
 #endif
 
-// Per-wave work counters.  The wave's slot in memory is read when the sweep starts
-// (tally_prefetch) and written back with the sums when it ends, so that the read-modify-write
-// does not add a memory round trip to the end of every wave.
-struct Tally {
-    unsigned long long c[kTallyN], base[kTallyN];
-    __device__ Tally() { for (int i = 0; i < kTallyN; ++i) { c[i] = 0; base[i] = 0; } }
-};
-__device__ __forceinline__ unsigned long long *tally_slot(const DevGraph &g) {
-    return g.tally + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kTallyN;
-}
-template <int... Idx>
-__device__ __forceinline__ void tally_prefetch(const DevGraph &g, Tally &t) {
-    if (lane_id() == 0) {
-        const unsigned long long *slot = tally_slot(g);
-        ((t.base[Idx] = slot[Idx]), ...);
-    }
+// Per-wave work counters: 32-bit while a sweep runs (one wave scans far fewer than 2^32 arcs in
+// one launch), added to the wave's 64-bit slot in memory when it ends.
+struct Tally { unsigned c[kTallyN]; __device__ Tally() { for (int i = 0; i < kTallyN; ++i) c[i] = 0; } };
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned x) {
+#pragma unroll
+    for (int d = 32; d; d >>= 1) x += __shfl_xor(x, d);
+    return x;
 }
 template <int... Idx>
 __device__ __forceinline__ void tally_flush(const DevGraph &g, Tally &t) {
-    unsigned long long any = 0;
+    unsigned any = 0;
     ((any |= t.c[Idx]), ...);
     if (!__ballot(any != 0)) return;
-    ((t.c[Idx] = wave_sum_u64(t.c[Idx])), ...);
+    ((t.c[Idx] = wave_sum_u32(t.c[Idx])), ...);
     if (lane_id() == 0) {
-        unsigned long long *slot = tally_slot(g);
-        ((slot[Idx] = t.base[Idx] + t.c[Idx]), ...);
+        unsigned long long *slot = g.tally + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kTallyN;
+        ((slot[Idx] += t.c[Idx]), ...);
     }
 }
 
@@ -527,7 +518,6 @@ __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
     const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
-    tally_prefetch<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds>(g, t);
     const int my_hub_vertex = hub_vertex_of_thread(g);
 #ifdef PSN_STAMPS
     PushStamps ps;
@@ -579,7 +569,6 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
     const unsigned rot = mix32(ct->epoch, (unsigned)k);
     SPAN_BEGIN(do_relabel ? 17u + 2u * (unsigned)k : 15u, (unsigned long long)do_relabel, 0);
     Tally t;
-    tally_prefetch<kTallyRelabels>(g, t);
     __shared__ unsigned s_app[2][kBlock / 64 + 1];
     const int span = kBlock * kVpt;
     for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
@@ -628,7 +617,6 @@ __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) {
     }
     const i64 eps = ct->eps, S = g.scale;
     Tally t;
-    tally_prefetch<kTallySat>(g, t);
     __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
     const HubAcc hb{s_add, s_max};
     hub_init(hb, kNegInf);
@@ -827,7 +815,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
     const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
-    tally_prefetch<kTallyGuScans, kTallyGuRelax, kTallyGuIters>(g, t);
     const int my_hub_vertex = hub_vertex_of_thread(g);
     const unsigned my_hub_row0 = my_hub_vertex >= 0 ? g.row[my_hub_vertex] : 0u, my_hub_row1 = my_hub_vertex >= 0 ? g.row[my_hub_vertex + 1] : 0u;
     i64 wmax = 0;
