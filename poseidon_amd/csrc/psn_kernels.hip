@@ -867,6 +867,32 @@ __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
 #endif
             STAMP(ts_s1);
             STAMP_ADD(acc_arcs, ts_s0, ts_s1);
+            // Rows made of aligned groups of parallel arcs (a machine row: eight slot arcs per class)
+            // give every lane one run plus its tail arc.  When the whole wave sees that shape, two
+            // candidates per lane are worked out and committed instead of going nine wide.
+            bool one_run = true;
+#pragma unroll
+            for (int j = 1; j < 8; ++j) one_run &= hd[j] == hd[0];
+            if (__all(one_run)) {
+                int c0 = INT32_MIN;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (rc9[j] > 0 && cs[j] > c0) c0 = cs[j];
+                const bool on0 = c0 != INT32_MIN, on1 = rc9[8] > 0;
+                int hd2[2] = {hd[0], hd[8]}, hub2[2];
+                i64 nd2[2] = {kDistInf, kDistInf};
+                const i64 p0 = on0 ? g.price[hd2[0]] : 0, p1 = on1 ? g.price[hd2[1]] : 0;
+                const i64 d0 = on0 ? ld_dist(g, hd2[0]) : 0, d1 = on1 ? ld_dist(g, hd2[1]) : 0;
+                hub2[0] = on0 ? g.hub_of[hd2[0]] : -1;
+                hub2[1] = on1 ? g.hub_of[hd2[1]] : -1;
+                if (on0) { const i64 l = arc_len(-(i64)c0 * S + p0 - pv, sh); if (dv + l < d0) nd2[0] = dv + l; }
+                if (on1) { const i64 l = arc_len(-(i64)cs[8] * S + p1 - pv, sh); if (dv + l < d1) nd2[1] = dv + l; }
+                STAMP(ts_f2);
+                STAMP_ADD(acc_gather, ts_s1, ts_f2);
+                gu_commit_batch<2>(g, q, dcnt, dlow, dseg, s_hmin, hd2, hub2, nd2, stamp, rot, wmax, t);
+                STAMP(ts_f3);
+                STAMP_ADD(acc_commit, ts_f2, ts_f3);
+                continue;
+            }
             i64 pu[9], du[9], nd[9];
             int hub[9];
             bool live[9];
