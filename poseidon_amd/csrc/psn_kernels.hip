@@ -91,6 +91,13 @@ constexpr unsigned kSpanEpoch0 = 40, kSpanEpochs = 8;
 #define PSN_STAMP_EXPAND_MIN 9000u  // per-wave records of the expand sweep; above any frontier: the push sweep records instead
 #endif
 constexpr unsigned kStampExpandMin = PSN_STAMP_EXPAND_MIN;
+#ifndef PSN_STAMP_EXPAND_MAX
+#define PSN_STAMP_EXPAND_MAX 4000000000u
+#endif
+constexpr unsigned kStampExpandMax = PSN_STAMP_EXPAND_MAX;
+#ifndef PSN_STAMP_PUSH
+#define PSN_STAMP_PUSH 1  // 0: the push sweep leaves the per-wave records to the expand sweep
+#endif
 __device__ __forceinline__ unsigned long long *span_slot(const DevGraph &g, unsigned slot) {
     const unsigned ep = g.ctrl->epoch - kSpanEpoch0;
     if (!g.stamps || ep >= kSpanEpochs || lane_id() != 0) return nullptr;
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyRounds]++;
     tally_flush<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds>(g, t);
 #ifdef PSN_STAMPS
-    if (g.stamps && nseg >= 200 && nseg < 3000 && nlow == 0 && lane_id() == 0) {
+    if (PSN_STAMP_PUSH && g.stamps && nseg >= 200 && nseg < 3000 && nlow == 0 && lane_id() == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long tk4 = stamp_now();
         unsigned long long *o = g.stamps + (size_t)wave * 16;
@@ -994,7 +1001,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
     }
     tally_flush<kTallyGuScans, kTallyGuRelax, kTallyGuIters>(g, t);
 #ifdef PSN_STAMPS
-    if (g.stamps && nseg >= kStampExpandMin && lane == 0) {
+    if (g.stamps && nseg >= kStampExpandMin && nseg < kStampExpandMax && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long ts_end = stamp_now();
         unsigned long long *o = g.stamps + (size_t)wave * 16;
