@@ -38,6 +38,7 @@ struct Sim {
     std::vector<i32> cap;
     int alpha = 8, gu_period = 8, sat_mode = 1;
     i64 eps0_cap = 0;  // if > 0: first epsilon is min(max scaled cost, eps0_cap * S)
+    int small_active = 0, small_period = 0;  // if > 0: with fewer active vertices than small_active, update every small_period rounds
     // stats
     i64 rounds = 0, scans = 0, pushes = 0, relabels = 0, gu_iters = 0, gu_scans = 0, gus = 0, sat_scans = 0;
     Sim(Graph &g_) : g(g_), S(g_.n + 1), price(g_.n, 0), excess(g_.supply), delta(g_.n, 0), cand(g_.n), dist(g_.n), cap(g_.cap) {}
@@ -129,7 +130,12 @@ struct Sim {
                 if (excess[u] > 0 && cand[u] <= price[u] && cand[u] != INT64_MIN) { price[u] = cand[u] - eps; ++relabels; }
             }
             for (i32 v = 0; v < g.n; ++v) cand[v] = INT64_MIN;
-            if (gu_period > 0 && local_round % gu_period == 0) global_update(eps);
+            {
+                static i64 since = 0;
+                ++since;
+                const i64 per = (small_active > 0 && (i64)act.size() < small_active) ? small_period : gu_period;
+                if (per > 0 && since >= per) { global_update(eps); since = 0; }
+            }
         }
         printf("  eps %-14ld rounds %-6ld scans %-12ld pushes %-9ld relabels %-9ld gu_iters %-5ld gu_scans %-11ld\n", (long)eps,
                (long)(rounds - r0), (long)(scans - s0), (long)(pushes - p0), (long)(relabels - l0), (long)(gu_iters - gi0), (long)(gu_scans - gs0));
@@ -154,6 +160,7 @@ int main(int argc, char **argv) {
     if (argc > 3) s.gu_period = atoi(argv[3]);
     if (argc > 4) s.sat_mode = atoi(argv[4]);
     if (argc > 5) s.eps0_cap = atoll(argv[5]);
+    if (argc > 7) { s.small_active = atoi(argv[6]); s.small_period = atoi(argv[7]); }
     auto t0 = std::chrono::steady_clock::now();
     i64 tc = s.solve();
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
