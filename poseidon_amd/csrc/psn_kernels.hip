@@ -183,34 +183,79 @@ __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
 // Vertex sweep helper: each thread brings VPT vertices (take[i], class, arc range); lane
 // and wave items are numbered by a popcount-style prefix inside the wave, waves are
 // chained through LDS, and the workgroup takes its slots with one atomic per list.
+// Split vertices (hubs) are staged in LDS first: one thread writing the ~70 segments of a
+// task class kept its whole workgroup alive three times longer than the rest of the sweep,
+// so the workgroup takes the slots for all staged vertices with one atomic and writes the
+// segments with all its threads.
+constexpr int kSplitCap = 128;  // split vertices staged per call; any beyond are written by their own thread
+struct AppendLds {
+    unsigned sums[2][kBlock / 64 + 1];
+    int v[kSplitCap], seg1[kSplitCap];
+    unsigned r0[kSplitCap], r1[kSplitCap], rot[kSplitCap], pref[kSplitCap + 1];
+    unsigned n, base;
+};
 template <int VPT>
 __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *segl, const bool (&take)[VPT], const int (&v)[VPT],
                                              const int (&cls)[VPT], const unsigned (&r0)[VPT], const unsigned (&r1)[VPT], unsigned rot,
-                                             unsigned (*lds)[kBlock / 64 + 1], const DevGraph *bounds = nullptr) {
+                                             AppendLds &lds, const DevGraph *bounds = nullptr) {
     unsigned nl = 0, ns = 0;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) { nl += take[i] && cls[i] == kClsLow; ns += take[i] && cls[i] == kClsMed; }
     const unsigned il = wave_incl_scan_u32(nl), is = wave_incl_scan_u32(ns);
     const int w = threadIdx.x >> 6;
-    if (lane_id() == 63) { lds[0][w] = il; lds[1][w] = is; }
+    if (lane_id() == 63) { lds.sums[0][w] = il; lds.sums[1][w] = is; }
+    if (threadIdx.x == 0) lds.n = 0;
     __syncthreads();
     if (threadIdx.x < 2) {
         unsigned tot = 0;
-        for (int i = 0; i < kBlock / 64; ++i) tot += lds[threadIdx.x][i];
-        lds[threadIdx.x][kBlock / 64] = tot ? aadd32(&cnt[threadIdx.x == 0 ? kClsLow : kClsSeg], tot) : 0u;
+        for (int i = 0; i < kBlock / 64; ++i) tot += lds.sums[threadIdx.x][i];
+        lds.sums[threadIdx.x][kBlock / 64] = tot ? aadd32(&cnt[threadIdx.x == 0 ? kClsLow : kClsSeg], tot) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {  // stage the split vertices while the slot atomics are in flight
+        if (take[i] && cls[i] == kClsHigh) {
+            const unsigned at = __hip_atomic_fetch_add(&lds.n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned vrot = rot ^ (unsigned)v[i] * 0x9E3779B9u;
+            int seg1 = 0;
+            if (bounds) { const int h = bounds->hub_of[v[i]]; if (h >= 0) seg1 = bounds->hub_seg0[h] + 1; }
+            if (at < (unsigned)kSplitCap) {
+                lds.v[at] = v[i]; lds.r0[at] = r0[i]; lds.r1[at] = r1[i]; lds.rot[at] = vrot; lds.seg1[at] = seg1;
+            } else {
+                append_split(cnt, segl, v[i], r0[i], r1[i], vrot, seg1);
+            }
+        }
     }
     __syncthreads();
-    unsigned pl = lds[0][kBlock / 64] + il - nl, ps = lds[1][kBlock / 64] + is - ns;
-    for (int i = 0; i < w; ++i) { pl += lds[0][i]; ps += lds[1][i]; }
+    unsigned pl = lds.sums[0][kBlock / 64] + il - nl, ps = lds.sums[1][kBlock / 64] + is - ns;
+    for (int i = 0; i < w; ++i) { pl += lds.sums[0][i]; ps += lds.sums[1][i]; }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         if (!take[i]) continue;
         if (cls[i] == kClsLow) lowl[pl++] = low_item(v[i], r0[i], r1[i]);
         else if (cls[i] == kClsMed) segl[ps++] = solo_item(v[i], r0[i], r1[i]);
-        else {  // rare: hubs
-            int seg1 = 0;
-            if (bounds) { const int h = bounds->hub_of[v[i]]; if (h >= 0) seg1 = bounds->hub_seg0[h] + 1; }
-            append_split(cnt, segl, v[i], r0[i], r1[i], rot ^ (unsigned)v[i] * 0x9E3779B9u, seg1);
+    }
+    const unsigned nsplit = min(lds.n, (unsigned)kSplitCap);  // workgroup-uniform
+    if (nsplit) {
+        if (threadIdx.x < 64) {  // first wave: segment counts -> exclusive prefix, then one atomic for all of them
+            unsigned run = 0;
+            for (unsigned b = 0; b < nsplit; b += 64) {
+                const unsigned i = b + threadIdx.x;
+                const unsigned c = i < nsplit ? (lds.r1[i] - lds.r0[i] + kWSeg - 1) / kWSeg : 0u;
+                const unsigned incl = wave_incl_scan_u32(c);
+                if (i < nsplit) lds.pref[i] = run + incl - c;
+                run += __shfl(incl, 63);
+            }
+            if (threadIdx.x == 0) { lds.pref[nsplit] = run; lds.base = aadd32(&cnt[kClsSeg], run); }
+        }
+        __syncthreads();
+        const unsigned total = lds.pref[nsplit], base = lds.base;
+        for (unsigned i = threadIdx.x; i < total; i += kBlock) {
+            unsigned lo = 0, hi = nsplit;  // staged vertex h with pref[h] <= i < pref[h + 1]
+            while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (lds.pref[mid] <= i) lo = mid; else hi = mid; }
+            const unsigned nseg = lds.pref[lo + 1] - lds.pref[lo];
+            const unsigned sg = (lds.rot[lo] % nseg + (i - lds.pref[lo])) % nseg;  // same rotated order as append_split
+            const unsigned a = lds.r0[lo] + sg * kWSeg;
+            segl[base + i] = make_int4(lds.v[lo], (int)a, (int)min(lds.r1[lo], a + kWSeg), lds.seg1[lo] ? (lds.seg1[lo] + (int)sg) << 1 : 0);
         }
     }
     __syncthreads();
@@ -576,7 +621,7 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
     const unsigned rot = mix32(ct->epoch, (unsigned)k);
     SPAN_BEGIN(do_relabel ? 17u + 2u * (unsigned)k : 15u, (unsigned long long)do_relabel, 0);
     Tally t;
-    __shared__ unsigned s_app[2][kBlock / 64 + 1];
+    __shared__ AppendLds s_app;
     const int span = kBlock * kVpt;
     for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
         bool act[kVpt];
@@ -1016,7 +1061,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
 __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_init_on) return;
-    __shared__ unsigned s_app[2][kBlock / 64 + 1];
+    __shared__ AppendLds s_app;
     const unsigned rot = mix32(ct->epoch, 0x5EEDu);
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < kGrid * (kBlock / 64); i += gridDim.x * kBlock) g.dmax_part[i] = 0;
     const int span = kBlock * kVpt;

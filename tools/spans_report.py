@@ -55,6 +55,17 @@ for ep, k in ((7, 5), (7, 9), (4, 3)):
         print("     waves living >= 8 us: count", len(longw), "indices", longw[:40], " their begins (us after first):", np.round((w[ep, sp, longw[:12], 0] - t0) / 100.0, 1))
         idle = hs & (np.arange(W) >= b[ep, sp, 3])
         print("     waves without an item: life mean %.2f us, begin (us after first) p50 %.1f max %.1f" % (lw[idle].mean(), np.percentile((w[ep, sp, idle, 0] - t0) / 100.0, 50), ((w[ep, sp, idle, 0] - t0) / 100.0).max()))
+for ep, k in ((6, 5), (7, 9)):
+    sr = 17 + 2 * k
+    if valid[ep, sr]:
+        lw = life[ep, sr] / 100.0
+        hs = has[ep, sr]
+        t0 = b[ep, sr, 0]
+        bg = (w[ep, sr, :, 0] - t0) / 100.0
+        print(f"  relabel epoch {ep} round {k}: waves {int(hs.sum())}, life mean {lw[hs].mean():.2f} p90 {np.percentile(lw[hs], 90):.2f} max {lw[hs].max():.2f} us; "
+              f"begin p50 {np.percentile(bg[hs], 50):.2f} p90 {np.percentile(bg[hs], 90):.2f} max {bg[hs].max():.2f}; span {(b[ep, sr, 1] - t0) / 100.0:.2f}")
+        order = np.argsort(-lw * hs)[:8]
+        print("     longest-lived waves", order, np.round(lw[order], 2), "begin", np.round(bg[order], 2))
 push = np.array(push)
 print("push launches", len(push), " relabel launches", len(rel))
 for lo, hi in ((0, 64), (64, 1024), (1024, 4096), (4096, 1 << 30)):
