@@ -330,17 +330,19 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
         hub_seg0[(size_t)i] = n_hub_segs;
         n_hub_segs += (int)((row[(size_t)hv + 1] - row[(size_t)hv] + kWSeg - 1) / kWSeg);
     }
+    std::vector<int> seg1_of((size_t)n, 0);
+    for (int i = 0; i < nhubs; ++i) seg1_of[(size_t)hub_vertex[(size_t)i]] = hub_seg0[(size_t)i] + 1;
     // ---- allocate
     DevGraph &g = c->g;
     g = DevGraph{};
     g.n = n;
     g.m2 = (unsigned)m2;
     g.scale = (i64)n + 1;
-    unsigned *d_row, *d_hub_row0; int *d_head, *d_rev, *d_tail, *d_hub_of, *d_hub_vertex, *d_hub_seg0; unsigned char *d_cls;
+    unsigned *d_row, *d_hub_row0; int *d_head, *d_rev, *d_tail, *d_hub_of, *d_hub_vertex, *d_hub_seg0, *d_seg1_of; unsigned char *d_cls;
     int rc;
 #define A(p, cnt) if ((rc = dalloc(c, &(p), (size_t)(cnt))) != PSN_OK) { free_graph_buffers(c); return rc; }
     A(d_row, n + 1) A(d_head, m2) A(c->d_cost, m2) A(d_rev, m2) A(d_tail, m2) A(c->d_ocap, m2) A(d_cls, n) A(d_hub_of, n) A(d_hub_vertex, kMaxHubs)
-    A(d_hub_row0, kMaxHubs) A(d_hub_seg0, kMaxHubs) A(g.seg_scan, n_hub_segs) A(g.seg_add[0], n_hub_segs) A(g.seg_add[1], n_hub_segs)
+    A(d_hub_row0, kMaxHubs) A(d_hub_seg0, kMaxHubs) A(d_seg1_of, n) A(g.seg_scan, n_hub_segs) A(g.seg_add[0], n_hub_segs) A(g.seg_add[1], n_hub_segs)
     A(g.cap, m2) A(g.rcap, m2) A(g.price, n) A(g.excess, n) A(g.cand, n) A(g.dist, n)
     A(c->d_supply, n) A(c->d_scalar, kScalarSlots)
     for (int i = 0; i < 2; ++i) { A(g.list_low[i], n) A(g.list_seg[i], (size_t)n + high_items) }
@@ -357,7 +359,7 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     c->d_head = d_head; c->d_rev = d_rev;
     g.row = d_row; g.head = d_head; g.cost = c->d_cost; g.rev = d_rev; g.tail = d_tail; g.ocap = c->d_ocap; g.cls = d_cls;
     g.hub_of = d_hub_of; g.hub_vertex = d_hub_vertex; g.nhubs = nhubs;
-    g.hub_row0 = d_hub_row0; g.hub_seg0 = d_hub_seg0; g.n_hub_segs = n_hub_segs;
+    g.hub_row0 = d_hub_row0; g.hub_seg0 = d_hub_seg0; g.seg1_of = d_seg1_of; g.n_hub_segs = n_hub_segs;
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(d_row, row.data(), sizeof(unsigned) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_cls, cls.data(), (size_t)n, hipMemcpyHostToDevice, s));
@@ -365,6 +367,7 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     HIPCHK(c, hipMemcpyAsync(d_hub_vertex, hub_vertex.data(), sizeof(int) * (size_t)kMaxHubs, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_hub_row0, hub_row0.data(), sizeof(unsigned) * (size_t)kMaxHubs, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_hub_seg0, hub_seg0.data(), sizeof(int) * (size_t)kMaxHubs, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_seg1_of, seg1_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_tail, tail.data(), sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_head, head, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_cost, cost, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
@@ -632,8 +635,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
         shift0 = ceil_log2(c0 * g.scale) - init.alpha_log2;
     } else {
         // the kept pseudoflow is v-optimal for v = largest violation: resume one step below it
-        shift0 = h_scalar[1] > 1 ? ceil_log2(h_scalar[1]) - init.alpha_log2 : 0;
-    }
+        shift0 = h_scalar[1] > 1 ? ceil_log2(h_scalar[1]) - init.alpha_log2 : 0;    }
     if (shift0 < 0) shift0 = 0;
     init.eps_shift = shift0;
     init.eps = (i64)1 << shift0;

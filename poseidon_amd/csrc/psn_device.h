@@ -58,6 +58,7 @@ struct DevGraph {
     const unsigned char *cls;
     const int *hub_of;      // hub slot of a vertex, -1 for the rest
     const int *hub_vertex;  // vertex of each hub slot
+    const int *seg1_of;     // per vertex: 1 + index of its first segment's bound slots when it is a hub, else 0
     int nhubs;
     // Per hub segment (wave item of a hub row): upper bounds on the largest key
     // price[head] - cost * S over the segment's residual arcs, so that the push sweep can skip

@@ -192,41 +192,60 @@ struct AppendLds {
     unsigned sums[2][kBlock / 64 + 1];
     int v[kSplitCap], seg1[kSplitCap];
     unsigned r0[kSplitCap], r1[kSplitCap], rot[kSplitCap], pref[kSplitCap + 1];
-    unsigned n, base;
+    unsigned n, nsegs;
 };
+// seg1[i]: 1 + index of the vertex's first bound slot when it is a hub whose segments carry bounds, else 0.
 template <int VPT>
 __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *segl, const bool (&take)[VPT], const int (&v)[VPT],
-                                             const int (&cls)[VPT], const unsigned (&r0)[VPT], const unsigned (&r1)[VPT], unsigned rot,
-                                             AppendLds &lds, const DevGraph *bounds = nullptr) {
+                                             const int (&cls)[VPT], const unsigned (&r0)[VPT], const unsigned (&r1)[VPT],
+                                             const int (&seg1)[VPT], unsigned rot, AppendLds &lds) {
     unsigned nl = 0, ns = 0;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) { nl += take[i] && cls[i] == kClsLow; ns += take[i] && cls[i] == kClsMed; }
     const unsigned il = wave_incl_scan_u32(nl), is = wave_incl_scan_u32(ns);
     const int w = threadIdx.x >> 6;
     if (lane_id() == 63) { lds.sums[0][w] = il; lds.sums[1][w] = is; }
-    if (threadIdx.x == 0) lds.n = 0;
+    if (threadIdx.x == 0) { lds.n = 0; lds.nsegs = 0; }
     __syncthreads();
-    if (threadIdx.x < 2) {
-        unsigned tot = 0;
-        for (int i = 0; i < kBlock / 64; ++i) tot += lds.sums[threadIdx.x][i];
-        lds.sums[threadIdx.x][kBlock / 64] = tot ? aadd32(&cnt[threadIdx.x == 0 ? kClsLow : kClsSeg], tot) : 0u;
-    }
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {  // stage the split vertices while the slot atomics are in flight
+    for (int i = 0; i < VPT; ++i) {  // stage the split vertices
         if (take[i] && cls[i] == kClsHigh) {
             const unsigned at = __hip_atomic_fetch_add(&lds.n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const unsigned vrot = rot ^ (unsigned)v[i] * 0x9E3779B9u;
-            int seg1 = 0;
-            if (bounds) { const int h = bounds->hub_of[v[i]]; if (h >= 0) seg1 = bounds->hub_seg0[h] + 1; }
             if (at < (unsigned)kSplitCap) {
-                lds.v[at] = v[i]; lds.r0[at] = r0[i]; lds.r1[at] = r1[i]; lds.rot[at] = vrot; lds.seg1[at] = seg1;
+                lds.v[at] = v[i]; lds.r0[at] = r0[i]; lds.r1[at] = r1[i]; lds.rot[at] = vrot; lds.seg1[at] = seg1[i];
+                __hip_atomic_fetch_add(&lds.nsegs, (r1[i] - r0[i] + kWSeg - 1) / kWSeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
-                append_split(cnt, segl, v[i], r0[i], r1[i], vrot, seg1);
+                append_split(cnt, segl, v[i], r0[i], r1[i], vrot, seg1[i]);
             }
         }
     }
     __syncthreads();
+    // One atomic per list takes the slots of the whole workgroup: lane items; wave items of the
+    // unsplit vertices followed by the segments of the staged ones.
+    const unsigned nsplit = min(lds.n, (unsigned)kSplitCap), nsplit_segs = lds.nsegs;  // workgroup-uniform
+    unsigned my_base = 0, my_tot = 0;
+    if (threadIdx.x < 2) {
+        for (int i = 0; i < kBlock / 64; ++i) my_tot += lds.sums[threadIdx.x][i];
+        const unsigned want = my_tot + (threadIdx.x == 1 ? nsplit_segs : 0u);
+        if (want) my_base = aadd32(&cnt[threadIdx.x == 0 ? kClsLow : kClsSeg], want);
+    }
+    if (nsplit && threadIdx.x < 64) {  // meanwhile: exclusive prefix of the staged vertices' segment counts
+        unsigned run = 0;
+        for (unsigned b = 0; b < nsplit; b += 64) {
+            const unsigned i = b + threadIdx.x;
+            const unsigned c = i < nsplit ? (lds.r1[i] - lds.r0[i] + kWSeg - 1) / kWSeg : 0u;
+            const unsigned incl = wave_incl_scan_u32(c);
+            if (i < nsplit) lds.pref[i] = run + incl - c;
+            run += __shfl(incl, 63);
+        }
+        if (threadIdx.x == 0) lds.pref[nsplit] = run;
+    }
+    if (threadIdx.x < 2) lds.sums[threadIdx.x][kBlock / 64] = my_base;
+    __syncthreads();
     unsigned pl = lds.sums[0][kBlock / 64] + il - nl, ps = lds.sums[1][kBlock / 64] + is - ns;
+    unsigned med_total = 0;
+    for (int i = 0; i < kBlock / 64; ++i) med_total += lds.sums[1][i];
     for (int i = 0; i < w; ++i) { pl += lds.sums[0][i]; ps += lds.sums[1][i]; }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -234,28 +253,29 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
         if (cls[i] == kClsLow) lowl[pl++] = low_item(v[i], r0[i], r1[i]);
         else if (cls[i] == kClsMed) segl[ps++] = solo_item(v[i], r0[i], r1[i]);
     }
-    const unsigned nsplit = min(lds.n, (unsigned)kSplitCap);  // workgroup-uniform
     if (nsplit) {
-        if (threadIdx.x < 64) {  // first wave: segment counts -> exclusive prefix, then one atomic for all of them
-            unsigned run = 0;
-            for (unsigned b = 0; b < nsplit; b += 64) {
-                const unsigned i = b + threadIdx.x;
-                const unsigned c = i < nsplit ? (lds.r1[i] - lds.r0[i] + kWSeg - 1) / kWSeg : 0u;
-                const unsigned incl = wave_incl_scan_u32(c);
-                if (i < nsplit) lds.pref[i] = run + incl - c;
-                run += __shfl(incl, 63);
+        // Wave w writes the staged vertices w, w + 4, ...: lane l first fetches the record of the
+        // l-th of them, the loop then hands one record at a time to the whole wave (lane reads, no
+        // LDS round trip per vertex) and the lanes write its segments side by side.
+        const unsigned base = lds.sums[1][kBlock / 64] + med_total;
+        const int l = lane_id();
+        const unsigned mine = (unsigned)w + (kBlock / 64) * (unsigned)l;
+        const bool have = mine < nsplit;
+        const int m_v = have ? lds.v[mine] : 0, m_s1 = have ? lds.seg1[mine] : 0;
+        const int m_r0 = have ? (int)lds.r0[mine] : 0, m_r1 = have ? (int)lds.r1[mine] : 0;
+        const int m_rot = have ? (int)lds.rot[mine] : 0, m_pref = have ? (int)lds.pref[mine] : 0;
+        const unsigned mine_cnt = nsplit > (unsigned)w ? (nsplit - (unsigned)w + kBlock / 64 - 1) / (kBlock / 64) : 0u;
+        for (unsigned j = 0; j < mine_cnt; ++j) {
+            const int hv = __builtin_amdgcn_readlane(m_v, j), hs1 = __builtin_amdgcn_readlane(m_s1, j);
+            const unsigned hr0 = (unsigned)__builtin_amdgcn_readlane(m_r0, j), hr1 = (unsigned)__builtin_amdgcn_readlane(m_r1, j);
+            const unsigned hrot = (unsigned)__builtin_amdgcn_readlane(m_rot, j), hpref = (unsigned)__builtin_amdgcn_readlane(m_pref, j);
+            const unsigned nseg = (hr1 - hr0 + kWSeg - 1) / kWSeg, first = hrot % nseg;
+            for (unsigned i = (unsigned)l; i < nseg; i += 64) {
+                unsigned sg = first + i;  // same rotated order as append_split
+                if (sg >= nseg) sg -= nseg;
+                const unsigned a = hr0 + sg * kWSeg;
+                segl[base + hpref + i] = make_int4(hv, (int)a, (int)min(hr1, a + kWSeg), hs1 ? (hs1 + (int)sg) << 1 : 0);
             }
-            if (threadIdx.x == 0) { lds.pref[nsplit] = run; lds.base = aadd32(&cnt[kClsSeg], run); }
-        }
-        __syncthreads();
-        const unsigned total = lds.pref[nsplit], base = lds.base;
-        for (unsigned i = threadIdx.x; i < total; i += kBlock) {
-            unsigned lo = 0, hi = nsplit;  // staged vertex h with pref[h] <= i < pref[h + 1]
-            while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (lds.pref[mid] <= i) lo = mid; else hi = mid; }
-            const unsigned nseg = lds.pref[lo + 1] - lds.pref[lo];
-            const unsigned sg = (lds.rot[lo] % nseg + (i - lds.pref[lo])) % nseg;  // same rotated order as append_split
-            const unsigned a = lds.r0[lo] + sg * kWSeg;
-            segl[base + i] = make_int4(lds.v[lo], (int)a, (int)min(lds.r1[lo], a + kWSeg), lds.seg1[lo] ? (lds.seg1[lo] + (int)sg) << 1 : 0);
         }
     }
     __syncthreads();
@@ -625,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
     const int span = kBlock * kVpt;
     for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
         bool act[kVpt];
-        int v[kVpt], cls[kVpt];
+        int v[kVpt], cls[kVpt], seg1[kVpt];
         unsigned r0[kVpt], r1[kVpt];
         i64 e[kVpt], c[kVpt], p[kVpt];
 #pragma unroll
@@ -638,6 +658,7 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
             p[i] = in ? g.price[v[i]] : 0;
             r0[i] = in ? g.row[v[i]] : 0;
             r1[i] = in ? g.row[v[i] + 1] : 0;
+            seg1[i] = in ? g.seg1_of[v[i]] : 0;
         }
 #pragma unroll
         for (int i = 0; i < kVpt; ++i) {
@@ -650,7 +671,7 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
             const i64 nc = act[i] ? kNegInf : kInf;
             if (v[i] < g.n && c[i] != nc) g.cand[v[i]] = nc;
         }
-        block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app, &g);
+        block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, seg1, rot, s_app);
     }
     tally_flush<kTallyRelabels>(g, t);
     SPAN_END(do_relabel ? 17u + 2u * (unsigned)k : 15u);
@@ -1079,7 +1100,8 @@ __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) {
         }
 #pragma unroll
         for (int i = 0; i < kVpt; ++i) { r0[i] = def[i] ? g.row[v[i]] : 0; r1[i] = def[i] ? g.row[v[i] + 1] : 0; }
-        block_append<kVpt>(ct->fr_cnt[0], g.fr_low[0], g.fr_seg[0], def, v, cls, r0, r1, rot, s_app);
+        const int no_bounds[kVpt] = {};  // frontier items carry no bound slots
+        block_append<kVpt>(ct->fr_cnt[0], g.fr_low[0], g.fr_seg[0], def, v, cls, r0, r1, no_bounds, rot, s_app);
     }
 }
 

@@ -54,7 +54,8 @@ for ep, k in ((7, 5), (7, 9), (4, 3)):
         longw = np.where(hs & (lw >= 8))[0]
         print("     waves living >= 8 us: count", len(longw), "indices", longw[:40], " their begins (us after first):", np.round((w[ep, sp, longw[:12], 0] - t0) / 100.0, 1))
         idle = hs & (np.arange(W) >= b[ep, sp, 3])
-        print("     waves without an item: life mean %.2f us, begin (us after first) p50 %.1f max %.1f" % (lw[idle].mean(), np.percentile((w[ep, sp, idle, 0] - t0) / 100.0, 50), ((w[ep, sp, idle, 0] - t0) / 100.0).max()))
+        if idle.any():
+            print("     waves without an item: life mean %.2f us, begin (us after first) p50 %.1f max %.1f" % (lw[idle].mean(), np.percentile((w[ep, sp, idle, 0] - t0) / 100.0, 50), ((w[ep, sp, idle, 0] - t0) / 100.0).max()))
 for ep, k in ((6, 5), (7, 9)):
     sr = 17 + 2 * k
     if valid[ep, sr]:
