@@ -190,16 +190,25 @@ __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
 constexpr int kSplitCap = 128;  // split vertices staged per call; any beyond are written by their own thread
 struct AppendLds {
     unsigned sums[2][kBlock / 64 + 1];
-    int v[kSplitCap], seg1[kSplitCap];
+    int v[kSplitCap];
     unsigned r0[kSplitCap], r1[kSplitCap], rot[kSplitCap], pref[kSplitCap + 1];
     unsigned n, nsegs;
+#ifdef PSN_PROBE_APPEND
+    unsigned long long *probe;
+#endif
 };
-// seg1[i]: 1 + index of the vertex's first bound slot when it is a hub whose segments carry bounds, else 0.
+// Items written here carry no bound slots: the relabel sweep handles the hubs, whose segments
+// do, outside this helper (one workgroup per hub).
 template <int VPT>
 __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *segl, const bool (&take)[VPT], const int (&v)[VPT],
                                              const int (&cls)[VPT], const unsigned (&r0)[VPT], const unsigned (&r1)[VPT],
-                                             const int (&seg1)[VPT], unsigned rot, AppendLds &lds) {
+                                             unsigned rot, AppendLds &lds, unsigned extra_segs = 0, unsigned *extra_base = nullptr) {
+    // extra_segs (workgroup-uniform): further wave-item slots the caller fills itself, taken with
+    // the same atomic; *extra_base receives the first of them.
     unsigned nl = 0, ns = 0;
+#ifdef PSN_PROBE_APPEND
+    const unsigned long long q0 = stamp_now();
+#endif
 #pragma unroll
     for (int i = 0; i < VPT; ++i) { nl += take[i] && cls[i] == kClsLow; ns += take[i] && cls[i] == kClsMed; }
     const unsigned il = wave_incl_scan_u32(nl), is = wave_incl_scan_u32(ns);
@@ -207,27 +216,33 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
     if (lane_id() == 63) { lds.sums[0][w] = il; lds.sums[1][w] = is; }
     if (threadIdx.x == 0) { lds.n = 0; lds.nsegs = 0; }
     __syncthreads();
+#ifdef PSN_PROBE_APPEND
+    const unsigned long long q1 = stamp_now();
+#endif
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {  // stage the split vertices
         if (take[i] && cls[i] == kClsHigh) {
             const unsigned at = __hip_atomic_fetch_add(&lds.n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const unsigned vrot = rot ^ (unsigned)v[i] * 0x9E3779B9u;
             if (at < (unsigned)kSplitCap) {
-                lds.v[at] = v[i]; lds.r0[at] = r0[i]; lds.r1[at] = r1[i]; lds.rot[at] = vrot; lds.seg1[at] = seg1[i];
+                lds.v[at] = v[i]; lds.r0[at] = r0[i]; lds.r1[at] = r1[i]; lds.rot[at] = vrot;
                 __hip_atomic_fetch_add(&lds.nsegs, (r1[i] - r0[i] + kWSeg - 1) / kWSeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
-                append_split(cnt, segl, v[i], r0[i], r1[i], vrot, seg1[i]);
+                append_split(cnt, segl, v[i], r0[i], r1[i], vrot);
             }
         }
     }
     __syncthreads();
+#ifdef PSN_PROBE_APPEND
+    const unsigned long long q2 = stamp_now();
+#endif
     // One atomic per list takes the slots of the whole workgroup: lane items; wave items of the
     // unsplit vertices followed by the segments of the staged ones.
     const unsigned nsplit = min(lds.n, (unsigned)kSplitCap), nsplit_segs = lds.nsegs;  // workgroup-uniform
     unsigned my_base = 0, my_tot = 0;
     if (threadIdx.x < 2) {
         for (int i = 0; i < kBlock / 64; ++i) my_tot += lds.sums[threadIdx.x][i];
-        const unsigned want = my_tot + (threadIdx.x == 1 ? nsplit_segs : 0u);
+        const unsigned want = my_tot + (threadIdx.x == 1 ? nsplit_segs + extra_segs : 0u);
         if (want) my_base = aadd32(&cnt[threadIdx.x == 0 ? kClsLow : kClsSeg], want);
     }
     if (nsplit && threadIdx.x < 64) {  // meanwhile: exclusive prefix of the staged vertices' segment counts
@@ -243,6 +258,9 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
     }
     if (threadIdx.x < 2) lds.sums[threadIdx.x][kBlock / 64] = my_base;
     __syncthreads();
+#ifdef PSN_PROBE_APPEND
+    const unsigned long long q3 = stamp_now();
+#endif
     unsigned pl = lds.sums[0][kBlock / 64] + il - nl, ps = lds.sums[1][kBlock / 64] + is - ns;
     unsigned med_total = 0;
     for (int i = 0; i < kBlock / 64; ++i) med_total += lds.sums[1][i];
@@ -253,6 +271,10 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
         if (cls[i] == kClsLow) lowl[pl++] = low_item(v[i], r0[i], r1[i]);
         else if (cls[i] == kClsMed) segl[ps++] = solo_item(v[i], r0[i], r1[i]);
     }
+#ifdef PSN_PROBE_APPEND
+    const unsigned long long q4 = stamp_now();
+#endif
+    if (extra_base) *extra_base = lds.sums[1][kBlock / 64] + med_total + nsplit_segs;
     if (nsplit) {
         // Wave w writes the staged vertices w, w + 4, ...: lane l first fetches the record of the
         // l-th of them, the loop then hands one record at a time to the whole wave (lane reads, no
@@ -261,12 +283,12 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
         const int l = lane_id();
         const unsigned mine = (unsigned)w + (kBlock / 64) * (unsigned)l;
         const bool have = mine < nsplit;
-        const int m_v = have ? lds.v[mine] : 0, m_s1 = have ? lds.seg1[mine] : 0;
+        const int m_v = have ? lds.v[mine] : 0;
         const int m_r0 = have ? (int)lds.r0[mine] : 0, m_r1 = have ? (int)lds.r1[mine] : 0;
         const int m_rot = have ? (int)lds.rot[mine] : 0, m_pref = have ? (int)lds.pref[mine] : 0;
         const unsigned mine_cnt = nsplit > (unsigned)w ? (nsplit - (unsigned)w + kBlock / 64 - 1) / (kBlock / 64) : 0u;
         for (unsigned j = 0; j < mine_cnt; ++j) {
-            const int hv = __builtin_amdgcn_readlane(m_v, j), hs1 = __builtin_amdgcn_readlane(m_s1, j);
+            const int hv = __builtin_amdgcn_readlane(m_v, j);
             const unsigned hr0 = (unsigned)__builtin_amdgcn_readlane(m_r0, j), hr1 = (unsigned)__builtin_amdgcn_readlane(m_r1, j);
             const unsigned hrot = (unsigned)__builtin_amdgcn_readlane(m_rot, j), hpref = (unsigned)__builtin_amdgcn_readlane(m_pref, j);
             const unsigned nseg = (hr1 - hr0 + kWSeg - 1) / kWSeg, first = hrot % nseg;
@@ -274,10 +296,22 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
                 unsigned sg = first + i;  // same rotated order as append_split
                 if (sg >= nseg) sg -= nseg;
                 const unsigned a = hr0 + sg * kWSeg;
-                segl[base + hpref + i] = make_int4(hv, (int)a, (int)min(hr1, a + kWSeg), hs1 ? (hs1 + (int)sg) << 1 : 0);
+                segl[base + hpref + i] = make_int4(hv, (int)a, (int)min(hr1, a + kWSeg), 0);
             }
         }
     }
+#ifdef PSN_PROBE_APPEND
+    {
+        const unsigned long long q5 = stamp_now();
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long q6 = stamp_now();
+        if (lds.probe && lane_id() == 0 && (nsplit || blockIdx.x == 5) && (unsigned long long)(nsplit + med_total) >= lds.probe[(size_t)(blockIdx.x * (kBlock / 64) + w) * 16 + 9]) {
+            unsigned long long *o = lds.probe + (size_t)(blockIdx.x * (kBlock / 64) + w) * 16;
+            o[9] = nsplit + med_total;
+            o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3; o[4] = q4; o[5] = q5; o[6] = q6; o[7] = nsplit; o[8] = nsplit_segs; o[13] = 4242;
+        }
+    }
+#endif
     __syncthreads();
 }
 
@@ -629,8 +663,41 @@ __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
 // the vertices, kVpt per thread.  cand[v] is +inf for vertices outside the list, so a
 // vertex that only became active during the push phase is never relabelled on partial
 // information.
+// Hubs are left out of the vertex sweep: workgroup h looks after hub h with all its threads.
+// The task classes sit next to each other, so the vertex sweep would hand all of them to one
+// workgroup, and one compute unit writes the ~4500 items of their segments several times
+// slower than the rest of the launch takes altogether.
+struct HubTurn { int v; bool act; unsigned r0, r1, nseg, first; int seg1; i64 e, c, p; };
+// every thread reads the same few words, so the turn needs no exchange inside the workgroup
+__device__ __forceinline__ HubTurn hub_fetch(const DevGraph &g, int hv) {
+    HubTurn h;
+    h.v = hv; h.e = g.excess[hv]; h.c = g.cand[hv]; h.p = g.price[hv];
+    h.r0 = g.row[hv]; h.r1 = g.row[hv + 1]; h.seg1 = g.seg1_of[hv];
+    return h;
+}
+__device__ __forceinline__ void hub_decide(const DevGraph &g, HubTurn &h, bool do_relabel, i64 eps, unsigned rot, Tally &t) {
+    h.act = h.e > 0;
+    h.nseg = (h.r1 - h.r0 + kWSeg - 1) / kWSeg;
+    h.first = (rot ^ (unsigned)h.v * 0x9E3779B9u) % h.nseg;
+    if (threadIdx.x == 0) {
+        if (h.act && do_relabel && h.c != kInf && h.c != kNegInf && h.c <= h.p) { g.price[h.v] = h.c - eps; t.c[kTallyRelabels]++; }
+        const i64 nc = h.act ? kNegInf : kInf;
+        if (h.c != nc) g.cand[h.v] = nc;
+    }
+}
+__device__ __forceinline__ void append_hub(const HubTurn &h, unsigned slot_base, int4 *segl) {
+    for (unsigned i = threadIdx.x; i < h.nseg; i += kBlock) {
+        unsigned sg = h.first + i;  // rotated order, as append_split
+        if (sg >= h.nseg) sg -= h.nseg;
+        const unsigned a = h.r0 + sg * kWSeg;
+        segl[slot_base + i] = make_int4(h.v, (int)a, (int)min(h.r1, a + kWSeg), (h.seg1 + (int)sg) << 1);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, int do_relabel) {
     Ctrl *ct = g.ctrl;
+    // the hub of this workgroup: fetched with the control words, one round trip for both
+    const int hub0 = (int)blockIdx.x < g.nhubs ? g.hub_vertex[blockIdx.x] : -1;
     if (!ct->rounds_on) return;
     const int dst = do_relabel ? (k + 1) & 1 : 0;
     if (do_relabel) {
@@ -642,6 +709,13 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
     SPAN_BEGIN(do_relabel ? 17u + 2u * (unsigned)k : 15u, (unsigned long long)do_relabel, 0);
     Tally t;
     __shared__ AppendLds s_app;
+    __shared__ unsigned s_hub_base;
+#ifdef PSN_PROBE_APPEND
+    if (threadIdx.x == 0) s_app.probe = do_relabel ? g.stamps : nullptr;
+#endif
+    HubTurn hub{};
+    if (hub0 >= 0) hub = hub_fetch(g, hub0);  // decided below, once the sweep's own loads are on their way too
+    int hub_state = hub0 >= 0 ? 1 : 0;  // 1: fetched, 2: dealt with
     const int span = kBlock * kVpt;
     for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
         bool act[kVpt];
@@ -658,20 +732,35 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
             p[i] = in ? g.price[v[i]] : 0;
             r0[i] = in ? g.row[v[i]] : 0;
             r1[i] = in ? g.row[v[i] + 1] : 0;
-            seg1[i] = in ? g.seg1_of[v[i]] : 0;
+            seg1[i] = in ? g.seg1_of[v[i]] : 1;
         }
+        unsigned hub_segs = 0, hub_base = 0;  // the hub's slots ride on the sweep's own slot atomic
+        if (hub_state == 1) { hub_decide(g, hub, do_relabel, eps, rot, t); hub_segs = hub.act ? hub.nseg : 0u; }
 #pragma unroll
         for (int i = 0; i < kVpt; ++i) {
-            act[i] = e[i] > 0;
+            act[i] = e[i] > 0 && seg1[i] == 0;  // not a hub (and inside the vertex range)
             if (!(act[i] && do_relabel && c[i] != kInf && c[i] != kNegInf)) p[i] = kNegInf;
         }
 #pragma unroll
         for (int i = 0; i < kVpt; ++i) {
             if (p[i] != kNegInf && c[i] <= p[i]) { g.price[v[i]] = c[i] - eps; t.c[kTallyRelabels]++; }
             const i64 nc = act[i] ? kNegInf : kInf;
-            if (v[i] < g.n && c[i] != nc) g.cand[v[i]] = nc;
+            if (seg1[i] == 0 && c[i] != nc) g.cand[v[i]] = nc;
         }
-        block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, seg1, rot, s_app);
+        block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app, hub_segs, &hub_base);
+        if (hub_state == 1) { if (hub.act) append_hub(hub, hub_base, g.list_seg[dst]); hub_state = 2; }
+    }
+    // hubs not dealt with above: this workgroup had no vertices to sweep, or the grid is smaller than the hub table
+    for (int hs = (int)blockIdx.x; hs < g.nhubs; hs += (int)gridDim.x) {
+        if (hs == (int)blockIdx.x && hub_state == 2) continue;
+        if (hs != (int)blockIdx.x) hub = hub_fetch(g, g.hub_vertex[hs]);
+        hub_decide(g, hub, do_relabel, eps, rot, t);
+        if (hub.act) {  // workgroup-uniform
+            if (threadIdx.x == 0) s_hub_base = aadd32(&ct->list_cnt[dst][kClsSeg], hub.nseg);
+            __syncthreads();
+            append_hub(hub, s_hub_base, g.list_seg[dst]);
+        }
+        __syncthreads();
     }
     tally_flush<kTallyRelabels>(g, t);
     SPAN_END(do_relabel ? 17u + 2u * (unsigned)k : 15u);
@@ -1083,6 +1172,9 @@ __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_init_on) return;
     __shared__ AppendLds s_app;
+#ifdef PSN_PROBE_APPEND
+    if (threadIdx.x == 0) s_app.probe = nullptr;
+#endif
     const unsigned rot = mix32(ct->epoch, 0x5EEDu);
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < kGrid * (kBlock / 64); i += gridDim.x * kBlock) g.dmax_part[i] = 0;
     const int span = kBlock * kVpt;
@@ -1100,8 +1192,7 @@ __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) {
         }
 #pragma unroll
         for (int i = 0; i < kVpt; ++i) { r0[i] = def[i] ? g.row[v[i]] : 0; r1[i] = def[i] ? g.row[v[i] + 1] : 0; }
-        const int no_bounds[kVpt] = {};  // frontier items carry no bound slots
-        block_append<kVpt>(ct->fr_cnt[0], g.fr_low[0], g.fr_seg[0], def, v, cls, r0, r1, no_bounds, rot, s_app);
+        block_append<kVpt>(ct->fr_cnt[0], g.fr_low[0], g.fr_seg[0], def, v, cls, r0, r1, rot, s_app);
     }
 }
 
