@@ -91,6 +91,31 @@ def test_random_graphs_with_hubs_and_large_caps(solver):
         assert rc == 0 and tc == r.total_cost
 
 
+@pytest.mark.parametrize("n_big,m", [(60, 100_000), (150, 400_000)])
+def test_more_split_vertices_than_sweep_workgroups_or_hub_slots(solver, n_big, m):
+    """Many vertices above the item size in a network small enough for the smallest sweep grid
+    (fewer workgroups than hubs: a workgroup looks after several), and more split vertices
+    than the 128 hub slots (the rest go through the staged append)."""
+    rng = np.random.default_rng(n_big)
+    n = 3000
+    big = rng.choice(n, n_big, replace=False)
+    tail = np.where(rng.random(m) < 0.85, big[rng.integers(0, n_big, m)], rng.integers(0, n, m))
+    head = rng.integers(0, n, m)
+    keep = tail != head
+    tail, head = tail[keep], head[keep]
+    cap = rng.integers(1, 50, tail.shape[0])
+    cost = rng.integers(0, 3000, tail.shape[0])
+    f = np.where(rng.random(tail.shape[0]) < 0.3, rng.integers(0, cap + 1), 0)
+    supply = np.zeros(n, np.int64)
+    np.add.at(supply, tail, f)
+    np.add.at(supply, head, -f)
+    g = synth.graph_from_arcs(n, tail, head, cap, cost, supply)
+    assert (np.diff(g.row_off) > 1152).sum() >= n_big * 0.9
+    r = solve_and_certify(solver, g)
+    rc, tc, _, _, _ = capi.cost_scaling(g)
+    assert rc == 0 and tc == r.total_cost
+
+
 def test_trivial_and_edge_cases(solver):
     # all supplies zero: nothing to route
     g = synth.graph_from_arcs(3, [0, 1], [1, 2], [2, 2], [1, 1], [0, 0, 0])
