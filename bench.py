@@ -71,14 +71,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libpsn has no CPU path")
+    # PSN_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share
+    # devices, collectives go through host tensors); the measured configuration is nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("PSN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    cdev = "cuda" if backend == "nccl" else "cpu"  # where collective operands live
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     seed = 1 + rank
     cl = pa.synth_cluster(args.config, seed)
@@ -89,14 +97,14 @@ def main():
     solver.upload(net)
     upload_s = time.perf_counter() - t0
     place = torch.empty(P, dtype=torch.int32, device="cuda")
-    gathered = torch.empty(world * P, dtype=torch.int32, device="cuda") if world > 1 else None
+    gathered = torch.empty(world * P, dtype=torch.int32, device=cdev) if world > 1 else None
 
     def step():
         solver.eval_costs(cl, net)             # K1: prices the class->machine slot arcs, resets the flow
         r = solver.solve()                     # cost-scaling push-relabel, cold start
         solver.placements_into(place.data_ptr())  # K5
         if world > 1:
-            dist.all_gather_into_tensor(gathered, place)
+            dist.all_gather_into_tensor(gathered, place if backend == "nccl" else place.cpu())
         return r
 
     def fence():
@@ -115,10 +123,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        costs = torch.tensor([res[-1].total_cost], dtype=torch.int64, device="cuda")
+        costs = torch.tensor([res[-1].total_cost], dtype=torch.int64, device=cdev)
         allc = [torch.empty_like(costs) for _ in range(world)]
         dist.all_gather(allc, costs)
         all_costs = [int(c.item()) for c in allc]
@@ -155,7 +163,7 @@ def main():
                     "kernel_ms": {k: round(v[0], 2) for k, v in kt.items()}}
         # ---- CPU baseline: the oracle's single-thread cost-scaling solver on the same network
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # timed on rank 0 of the single-GPU run only
             from oracle import capi, synth
             ocl = synth.make_cluster(args.config, seed)
             og = synth.build_graph(ocl)
@@ -174,7 +182,7 @@ def main():
                       "cost-scaling solve + placement extraction, 10k-node/100k-pod graph)",
             "value": round(arcs_per_s, 1), "unit": "arcs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int64", "data": "synthetic",
+            "dtype": "int64", "data": "synthetic" if backend == "nccl" else f"synthetic (rehearsal over {backend}: not a measurement)",
             "config": {"workload": f"psn-synth-v1 config {args.config}: {cl.layout.n_machines} machines / {P} pods, "
                                    f"n={net.n} vertices, m={net.m} forward arcs, one network per GPU (seed = 1 + rank)",
                        "graphs_per_step": world, "alpha": 16, "rounds_per_global_update": 12},
