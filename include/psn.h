@@ -170,12 +170,15 @@ int psn_settle_sources(psn_ctx *ctx, int64_t count, const int32_t *vertex, int64
 int psn_solve(psn_ctx *ctx, uint32_t flags, psn_result *out);
 
 /* Solve `count` independent networks, one per context (each uploaded and priced
- * beforehand, all contexts distinct), with `workers` host threads (0 -> 4) so that the
- * kernels of several small networks share the GPU through their contexts' streams.
- * out[i] receives the result of ctxs[i]; the first error code is returned, the other
- * solves still run.  This is the batch of what-if scheduling rounds: each is the same
- * Schedule solve (/root/reference/pkg/firmament/firmament_scheduler.proto:17) on its own
- * cluster state. */
+ * beforehand, all contexts distinct).  Contexts on one device with the same solver
+ * configuration are solved in lockstep groups of up to 64 (environment PSN_BATCH_GROUP:
+ * 1..128; 1 = one at a time): every stage of the solve is one launch for the whole group,
+ * which is what bounds many small networks; the networks share nothing and each stops
+ * when it is done.  Groups are spread over `workers` host threads (0 -> 4), each driving
+ * one stream.  out[i] receives the result of ctxs[i] (solve_ms of a group member is the
+ * group's time); the first error code is returned, the other solves still run.  This is
+ * the batch of what-if scheduling rounds: each is the same Schedule solve
+ * (/root/reference/pkg/firmament/firmament_scheduler.proto:17) on its own cluster state. */
 int psn_solve_batch(psn_ctx *const *ctxs, int32_t count, uint32_t flags, int32_t workers,
                     psn_result *out);
 

@@ -15,6 +15,8 @@
 
 #include "../../include/psn.h"
 #include "psn_device.h"
+#include <chrono>
+#include <cstdio>
 #include "psn_kernels.hip"  // one translation unit: kernels are launched from this file
 
 using namespace psn;
@@ -592,17 +594,11 @@ int psn_update_supplies(psn_ctx *c, int64_t count, const int32_t *vertex, const 
     return PSN_OK;
 }
 
-int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
-    if (!c || !out) return fail(c, PSN_EINVAL, "null argument");
-    std::memset(out, 0, sizeof(*out));
-    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
-    const bool warm = (flags & PSN_WARM_START) && c->solved;
-    HIPCHK(c, hipSetDevice(c->device));
-    for (int i = 0; i < PSN_KT_CLASSES; ++i) { c->kt_ms[i] = 0; c->kt_calls[i] = 0; }
-    hipStream_t s = c->stream;
+// ---- a solve in pieces, shared by the single-network call and the lockstep group
+// Launches that bring the working state to the start of a solve and ask for the statistics the
+// first epsilon is derived from (h_scalar: kScalarSlots words, read after the stream has drained).
+static int solve_prepare(psn_ctx *c, hipStream_t s, bool warm, i64 *h_scalar) {
     const DevGraph &g = c->g;
-    // supplies must still balance (psn_update_supplies may have changed them)
-    HIPCHK(c, hipEventRecord(c->ev0, s));
     hipLaunchKernelGGL(k_reset, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_supply, warm ? 1 : 0);
     hipLaunchKernelGGL(k_mirror, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_supply, warm ? 1 : 0);
     if (warm) hipLaunchKernelGGL(k_excess_from_flow, dim3(kGrid), dim3(kBlock), 0, s, g);
@@ -611,9 +607,12 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     if (g.dbg_cnt) HIPCHK(c, hipMemsetAsync(g.dbg_cnt, 0, sizeof(unsigned), s));
     if (!warm) hipLaunchKernelGGL(k_cost_stats, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 2);
     if (warm) hipLaunchKernelGGL(k_max_violation, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 1);
-    i64 h_scalar[kScalarSlots] = {};
-    HIPCHK(c, hipMemcpyAsync(h_scalar, c->d_scalar, sizeof(h_scalar), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemcpyAsync(h_scalar, c->d_scalar, kScalarSlots * sizeof(i64), hipMemcpyDeviceToHost, s));
+    return PSN_OK;
+}
+// The control block a solve starts from (into the context's pinned copy) and its upload.
+static int solve_start(psn_ctx *c, hipStream_t s, bool warm, const i64 *h_scalar) {
+    const DevGraph &g = c->g;
     Ctrl init{};
     init.alpha_log2 = c->cfg.alpha_log2;
     int shift0;
@@ -635,13 +634,63 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
         shift0 = ceil_log2(c0 * g.scale) - init.alpha_log2;
     } else {
         // the kept pseudoflow is v-optimal for v = largest violation: resume one step below it
-        shift0 = h_scalar[1] > 1 ? ceil_log2(h_scalar[1]) - init.alpha_log2 : 0;    }
+        shift0 = h_scalar[1] > 1 ? ceil_log2(h_scalar[1]) - init.alpha_log2 : 0;
+    }
     if (shift0 < 0) shift0 = 0;
     init.eps_shift = shift0;
     init.eps = (i64)1 << shift0;
     init.need_sat = 1;
     *c->h_ctrl = init;
     HIPCHK(c, hipMemcpyAsync(g.ctrl, c->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice, s));
+    return PSN_OK;
+}
+// Objective and work counters of the finished solve (h_cost: 1 word, h_tally: kTallyN words, and
+// the context's pinned control block; all valid after the stream has drained).
+static int solve_finish(psn_ctx *c, hipStream_t s, i64 *h_cost, unsigned long long *h_tally) {
+    const DevGraph &g = c->g;
+    hipLaunchKernelGGL(k_total_cost, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar);
+    hipLaunchKernelGGL(k_tally_sum, dim3(1), dim3(64 * kTallyN), 0, s, g, c->d_tally_out, c->tally_slots);
+    HIPCHK(c, hipMemcpyAsync(h_cost, c->d_scalar, sizeof(i64), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(h_tally, c->d_tally_out, kTallyN * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_ctrl, g.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+    return PSN_OK;
+}
+static void solve_report(psn_ctx *c, psn_result *out, int status, i64 cost, const unsigned long long *h_tally, long long replays,
+                         int launches_per_replay, float ms) {
+    out->total_cost = cost;
+    out->status = status;
+    out->refines = (int32_t)c->h_ctrl->tally_refines;
+    out->arc_scans = h_tally[kTallyScans];
+    out->pushes = h_tally[kTallyPushes];
+    out->relabels = h_tally[kTallyRelabels];
+    out->vertex_visits = h_tally[kTallyVisits];
+    out->gu_arc_scans = h_tally[kTallyGuScans];
+    out->gu_relaxations = h_tally[kTallyGuRelax];
+    out->sat_arc_scans = h_tally[kTallySat];
+    out->rounds = h_tally[kTallyRounds];
+    out->gu_iterations = h_tally[kTallyGuIters];
+    out->global_updates = c->h_ctrl->tally_gus;
+    out->launches = (uint64_t)replays * (uint64_t)launches_per_replay;
+    out->solve_ms = ms;
+    c->solved = status == PSN_OK;
+}
+
+int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
+    if (!c || !out) return fail(c, PSN_EINVAL, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    const bool warm = (flags & PSN_WARM_START) && c->solved;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < PSN_KT_CLASSES; ++i) { c->kt_ms[i] = 0; c->kt_calls[i] = 0; }
+    hipStream_t s = c->stream;
+    const DevGraph &g = c->g;
+    // supplies must still balance (psn_update_supplies may have changed them)
+    HIPCHK(c, hipEventRecord(c->ev0, s));
+    i64 h_scalar[kScalarSlots] = {};
+    int rc = solve_prepare(c, s, warm, h_scalar);
+    if (rc != PSN_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(s));
+    if ((rc = solve_start(c, s, warm, h_scalar)) != PSN_OK) return rc;
     // ---- replay until done
     const long long max_replays = 200000;
     long long replays = 0;
@@ -669,34 +718,137 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
         if (c->h_ctrl->done) break;
         if (replays >= max_replays) { status = PSN_ELIMIT; break; }
     }
-    hipLaunchKernelGGL(k_total_cost, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar);
-    hipLaunchKernelGGL(k_tally_sum, dim3(1), dim3(64 * kTallyN), 0, s, g, c->d_tally_out, c->tally_slots);
     unsigned long long h_tally[kTallyN];
-    HIPCHK(c, hipMemcpyAsync(h_scalar, c->d_scalar, sizeof(i64), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(h_tally, c->d_tally_out, sizeof(h_tally), hipMemcpyDeviceToHost, s));
+    i64 h_cost = 0;
+    if ((rc = solve_finish(c, s, &h_cost, h_tally)) != PSN_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, s));
     HIPCHK(c, hipStreamSynchronize(s));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    out->total_cost = h_scalar[0];
-    out->status = status;
-    out->refines = (int32_t)c->h_ctrl->tally_refines;
-    out->arc_scans = h_tally[kTallyScans];
-    out->pushes = h_tally[kTallyPushes];
-    out->relabels = h_tally[kTallyRelabels];
-    out->vertex_visits = h_tally[kTallyVisits];
-    out->gu_arc_scans = h_tally[kTallyGuScans];
-    out->gu_relaxations = h_tally[kTallyGuRelax];
-    out->sat_arc_scans = h_tally[kTallySat];
-    out->rounds = h_tally[kTallyRounds];
-    out->gu_iterations = h_tally[kTallyGuIters];
-    out->global_updates = c->h_ctrl->tally_gus;
-    out->launches = (uint64_t)replays * (uint64_t)c->launches_per_replay;
-    out->solve_ms = ms;
-    c->solved = status == PSN_OK;
+    solve_report(c, out, status, h_cost, h_tally, replays, c->launches_per_replay, ms);
     if (status != PSN_OK) return fail(c, status, "solve did not converge");
     return PSN_OK;
 }
+
+// ---- lockstep group: several resident networks advance through one replay sequence
+// One launch per stage serves every network of the group (blockIdx.y picks it), so a group of
+// G small networks costs the launches of one.  Members must live on one device and share the
+// solver configuration; everything runs on the first member's stream.
+namespace {
+constexpr int kMaxGroup = 128;
+
+int group_enqueue_replay(const std::vector<psn_ctx *> &m, const DevGraph *d_graphs, int *d_status, hipStream_t s, int *launches_out) {
+    const unsigned G = (unsigned)m.size();
+    int gv = 1, gv1 = 1, gs = 32, launches = 0;
+    for (psn_ctx *c : m) {
+        gv = std::max(gv, std::min(kGrid, (c->g.n + kBlock * kVpt - 1) / (kBlock * kVpt)));
+        gv1 = std::max(gv1, std::min(kGrid, (c->g.n + kBlock - 1) / kBlock));
+        gs = std::max<int>(gs, (int)std::min<long long>(kGrid, (c->m2 + kBlock * 16 - 1) / (kBlock * 16)));
+    }
+    const int rounds = m[0]->rounds;
+#define LG(kern, grid, ...) do { hipLaunchKernelGGL(kern, dim3(grid, G), dim3(kBlock), 0, s, d_graphs, ##__VA_ARGS__); ++launches; } while (0)
+    hipLaunchKernelGGL(k_begin_group, dim3(1, G), dim3(1), 0, s, d_graphs); ++launches;
+    LG(k_saturate_group, gs);
+    LG(k_gu_init_group, gv);
+    for (int k = 0; k < kGuIters; ++k) LG(k_gu_expand_group, gs, k);
+    hipLaunchKernelGGL(k_mid_group, dim3(1, G), dim3(1), 0, s, d_graphs, kGuIters); ++launches;
+    LG(k_gu_apply_group, gv1);
+    LG(k_relabel_compact_group, gv, 0, 0);
+    for (int k = 0; k < rounds; ++k) {
+        LG(k_push_group, gs, k);
+        LG(k_relabel_compact_group, gv, k, 1);
+    }
+    hipLaunchKernelGGL(k_end_group, dim3(1, G), dim3(1), 0, s, d_graphs, rounds); ++launches;
+    hipLaunchKernelGGL(k_group_status, dim3(1), dim3(kMaxGroup), 0, s, d_graphs, (int)G, d_status); ++launches;
+#undef LG
+    *launches_out = launches;
+    return PSN_OK;
+}
+
+// Solves the members together; out[i] belongs to m[i].  Returns the first member's error, if any.
+int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *const *out) {
+    psn_ctx *lead = m[0];
+    const size_t G = m.size();
+    hipStream_t s = lead->stream;
+    HIPCHK(lead, hipSetDevice(lead->device));
+    DevGraph *d_graphs = nullptr;
+    int *d_status = nullptr, *h_status = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    std::vector<i64> h_scalar(G * kScalarSlots, 0), h_cost(G, 0);
+    std::vector<unsigned long long> h_tally(G * kTallyN, 0);
+    std::vector<char> warm(G, 0);
+    std::vector<int> status(G, PSN_OK);
+    int rc = PSN_OK, launches = 0;
+    long long replays = 0;
+    float ms = 0.f;
+    auto cleanup = [&]() {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (d_graphs) (void)hipFree(d_graphs);
+        if (d_status) (void)hipFree(d_status);
+        if (h_status) (void)hipHostFree(h_status);
+    };
+#define GCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = fail(lead, PSN_EDEVICE, #call, e_); cleanup(); return rc; } } while (0)
+    const bool dbg_t = std::getenv("PSN_DEBUG_GROUP") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_a = now(), t_b = 0, t_c = 0, t_d = 0, t_e = 0;
+    GCHK(hipMalloc((void **)&d_graphs, G * sizeof(DevGraph)));
+    GCHK(hipMalloc((void **)&d_status, 2 * G * sizeof(int)));
+    GCHK(hipHostMalloc((void **)&h_status, 2 * G * sizeof(int), hipHostMallocDefault));
+    std::vector<DevGraph> h_graphs(G);
+    for (size_t i = 0; i < G; ++i) {
+        std::memset(out[i], 0, sizeof(psn_result));
+        h_graphs[i] = m[i]->g;
+        warm[i] = (flags & PSN_WARM_START) && m[i]->solved;
+    }
+    GCHK(hipEventRecord(lead->ev0, s));
+    GCHK(hipMemcpyAsync(d_graphs, h_graphs.data(), G * sizeof(DevGraph), hipMemcpyHostToDevice, s));
+    for (size_t i = 0; i < G; ++i)
+        if ((rc = solve_prepare(m[i], s, warm[i], &h_scalar[i * kScalarSlots])) != PSN_OK) { cleanup(); return rc; }
+    GCHK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < G; ++i)
+        if ((rc = solve_start(m[i], s, warm[i], &h_scalar[i * kScalarSlots])) != PSN_OK) { cleanup(); return rc; }
+    t_b = now();
+    GCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    group_enqueue_replay(m, d_graphs, d_status, s, &launches);
+    GCHK(hipStreamEndCapture(s, &graph));
+    GCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    t_c = now();
+    const long long max_replays = 200000;
+    for (;;) {
+        GCHK(hipGraphLaunch(gexec, s));
+        ++replays;
+        GCHK(hipMemcpyAsync(h_status, d_status, 2 * G * sizeof(int), hipMemcpyDeviceToHost, s));
+        GCHK(hipStreamSynchronize(s));
+        bool all = true;
+        for (size_t i = 0; i < G; ++i) all = all && (h_status[2 * i] || h_status[2 * i + 1]);
+        if (all) break;
+        if (replays >= max_replays) {
+            for (size_t i = 0; i < G; ++i) if (!h_status[2 * i] && !h_status[2 * i + 1]) status[i] = PSN_ELIMIT;
+            break;
+        }
+    }
+    t_d = now();
+    for (size_t i = 0; i < G; ++i) {
+        if (h_status[2 * i + 1]) status[i] = h_status[2 * i + 1] == PSN_EINFEASIBLE_DEV ? PSN_EINFEASIBLE : PSN_EDEVICE;
+        if ((rc = solve_finish(m[i], s, &h_cost[i], &h_tally[i * kTallyN])) != PSN_OK) { cleanup(); return rc; }
+    }
+    GCHK(hipEventRecord(lead->ev1, s));
+    GCHK(hipStreamSynchronize(s));
+    GCHK(hipEventElapsedTime(&ms, lead->ev0, lead->ev1));
+#undef GCHK
+    t_e = now();
+    cleanup();
+    if (dbg_t) fprintf(stderr, "group of %zu: alloc+prepare %.2f capture+instantiate %.2f replays(%lld) %.2f finish %.2f cleanup %.2f ms\n", G, t_b - t_a, t_c - t_b, replays, t_d - t_c, t_e - t_d, now() - t_e);
+    rc = PSN_OK;
+    for (size_t i = 0; i < G; ++i) {
+        solve_report(m[i], out[i], status[i], h_cost[i], &h_tally[i * kTallyN], replays, launches, ms);
+        if (status[i] != PSN_OK) { (void)fail(m[i], status[i], "solve did not converge"); if (rc == PSN_OK) rc = status[i]; }
+    }
+    return rc;
+}
+}  // namespace
 
 int psn_solve_batch(psn_ctx *const *ctxs, int32_t count, uint32_t flags, int32_t workers, psn_result *out) {
     if (count < 0 || (count > 0 && (!ctxs || !out))) return PSN_EINVAL;
@@ -704,15 +856,50 @@ int psn_solve_batch(psn_ctx *const *ctxs, int32_t count, uint32_t flags, int32_t
     for (int32_t i = 0; i < count; ++i)
         for (int32_t j = i + 1; j < count; ++j)
             if (ctxs[i] == ctxs[j]) return PSN_EINVAL;  // a context runs one solve at a time
+    for (int32_t i = 0; i < count; ++i) if (!ctxs[i]->uploaded) return fail(ctxs[i], PSN_ESTATE, "no graph uploaded");
     if (workers <= 0) workers = 4;
-    workers = std::min<int32_t>(workers, std::max<int32_t>(count, 1));
-    std::atomic<int32_t> next{0};
+    // Contexts that can share a replay sequence (same device, same solver configuration, graph
+    // replay on) are solved in lockstep groups; the groups are spread over the worker threads.
+    int group_cap = 64;
+    if (const char *ev = std::getenv("PSN_BATCH_GROUP")) group_cap = std::max(1, std::min(kMaxGroup, atoi(ev)));
+    std::vector<std::vector<int32_t>> groups;
+    {
+        std::vector<char> taken((size_t)count, 0);
+        // even group sizes: ceil(eligible / ceil(eligible / cap)) members each
+        for (int32_t i = 0; i < count; ++i) {
+            if (taken[(size_t)i]) continue;
+            std::vector<int32_t> same{i};
+            taken[(size_t)i] = 1;
+            const psn_ctx *a = ctxs[i];
+            const bool groupable = !(a->cfg.flags & (PSN_CFG_EAGER | PSN_CFG_KTIME)) && group_cap > 1;
+            for (int32_t j = i + 1; groupable && j < count; ++j) {
+                const psn_ctx *b = ctxs[j];
+                if (!taken[(size_t)j] && b->device == a->device && b->cfg.flags == a->cfg.flags && b->cfg.alpha_log2 == a->cfg.alpha_log2 &&
+                    b->rounds == a->rounds) { same.push_back(j); taken[(size_t)j] = 1; }
+            }
+            const size_t parts = (same.size() + (size_t)group_cap - 1) / (size_t)group_cap;
+            const size_t per = (same.size() + parts - 1) / parts;
+            for (size_t at = 0; at < same.size(); at += per)
+                groups.emplace_back(same.begin() + (long)at, same.begin() + (long)std::min(same.size(), at + per));
+        }
+    }
+    workers = std::min<int32_t>(workers, std::max<int32_t>((int32_t)groups.size(), 1));
+    std::atomic<size_t> next{0};
     std::atomic<int> first_error{PSN_OK};
     auto work = [&]() {
         for (;;) {
-            const int32_t i = next.fetch_add(1);
-            if (i >= count) return;
-            const int rc = psn_solve(ctxs[i], flags, &out[i]);
+            const size_t gi = next.fetch_add(1);
+            if (gi >= groups.size()) return;
+            const std::vector<int32_t> &ids = groups[gi];
+            int rc;
+            if (ids.size() == 1) {
+                rc = psn_solve(ctxs[ids[0]], flags, &out[ids[0]]);
+            } else {
+                std::vector<psn_ctx *> m;
+                std::vector<psn_result *> o;
+                for (int32_t id : ids) { m.push_back(ctxs[id]); o.push_back(&out[id]); }
+                rc = solve_group(m, flags, o.data());
+            }
             if (rc != PSN_OK) { int expected = PSN_OK; first_error.compare_exchange_strong(expected, rc); }
         }
     };

@@ -92,6 +92,16 @@ __global__ void k_gu_apply(DevGraph g);
 __global__ void k_begin(DevGraph g);
 __global__ void k_mid(DevGraph g, int n_iters);
 __global__ void k_end(DevGraph g, int n_rounds);
+__global__ void k_push_group(const DevGraph *gs, int k);
+__global__ void k_relabel_compact_group(const DevGraph *gs, int k, int do_relabel);
+__global__ void k_saturate_group(const DevGraph *gs);
+__global__ void k_gu_init_group(const DevGraph *gs);
+__global__ void k_gu_expand_group(const DevGraph *gs, int k);
+__global__ void k_gu_apply_group(const DevGraph *gs);
+__global__ void k_begin_group(const DevGraph *gs);
+__global__ void k_mid_group(const DevGraph *gs, int n_iters);
+__global__ void k_end_group(const DevGraph *gs, int n_rounds);
+__global__ void k_group_status(const DevGraph *gs, int count, int *status);
 __global__ void k_reset(DevGraph g, const i64 *supply, int keep_flow);
 __global__ void k_mirror(DevGraph g, const i64 *supply, int recompute_excess);
 __global__ void k_excess_from_flow(DevGraph g);

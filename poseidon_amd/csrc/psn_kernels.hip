@@ -602,7 +602,7 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
     STAMP_ADD(ps.tail, tq0, tq1);
 }
 
-__global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) {
+__device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     Ctrl *ct = g.ctrl;
     if (!ct->rounds_on) return;
     const unsigned *cnt = ct->list_cnt[k & 1];
@@ -694,34 +694,16 @@ __device__ __forceinline__ void append_hub(const HubTurn &h, unsigned slot_base,
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, int do_relabel) {
+__device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, int do_relabel) {
+    STAMP(t_entry);
     Ctrl *ct = g.ctrl;
-    // the hub of this workgroup: fetched with the control words, one round trip for both
-    const int hub0 = (int)blockIdx.x < g.nhubs ? g.hub_vertex[blockIdx.x] : -1;
-    if (!ct->rounds_on) return;
-    const int dst = do_relabel ? (k + 1) & 1 : 0;
-    if (do_relabel) {
-        const unsigned *cnt = ct->list_cnt[k & 1];
-        if (cnt[kClsLow] + cnt[kClsSeg] == 0) return;  // nothing was active
-    }
-    const i64 eps = ct->eps;
-    const unsigned rot = mix32(ct->epoch, (unsigned)k);
-    SPAN_BEGIN(do_relabel ? 17u + 2u * (unsigned)k : 15u, (unsigned long long)do_relabel, 0);
-    Tally t;
-    __shared__ AppendLds s_app;
-    __shared__ unsigned s_hub_base;
-#ifdef PSN_PROBE_APPEND
-    if (threadIdx.x == 0) s_app.probe = do_relabel ? g.stamps : nullptr;
-#endif
-    HubTurn hub{};
-    if (hub0 >= 0) hub = hub_fetch(g, hub0);  // decided below, once the sweep's own loads are on their way too
-    int hub_state = hub0 >= 0 ? 1 : 0;  // 1: fetched, 2: dealt with
+    // The first batch of vertex words is asked for before the control words are known: both
+    // arrive in one round trip, and a launch that turns out to be switched off just drops them.
     const int span = kBlock * kVpt;
-    for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
-        bool act[kVpt];
-        int v[kVpt], cls[kVpt], seg1[kVpt];
-        unsigned r0[kVpt], r1[kVpt];
-        i64 e[kVpt], c[kVpt], p[kVpt];
+    int v[kVpt], cls[kVpt], seg1[kVpt];
+    unsigned r0[kVpt], r1[kVpt];
+    i64 e[kVpt], c[kVpt], p[kVpt];
+    auto fetch = [&](int base) {
 #pragma unroll
         for (int i = 0; i < kVpt; ++i) {  // everything in one round trip: the sweep is latency-bound
             v[i] = base + i * kBlock + (int)threadIdx.x;
@@ -734,6 +716,31 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
             r1[i] = in ? g.row[v[i] + 1] : 0;
             seg1[i] = in ? g.seg1_of[v[i]] : 1;
         }
+    };
+    fetch((int)blockIdx.x * span);
+    // the hub of this workgroup: fetched with the control words as well
+    const int hub0 = (int)blockIdx.x < g.nhubs ? g.hub_vertex[blockIdx.x] : -1;
+    if (!ct->rounds_on) return;
+    const int dst = do_relabel ? (k + 1) & 1 : 0;
+    if (do_relabel) {
+        const unsigned *cnt = ct->list_cnt[k & 1];
+        if (cnt[kClsLow] + cnt[kClsSeg] == 0) return;  // nothing was active
+    }
+    const i64 eps = ct->eps;
+    const unsigned rot = mix32(ct->epoch, (unsigned)k);
+    SPAN_BEGIN(do_relabel ? 17u + 2u * (unsigned)k : 15u, (unsigned long long)do_relabel, stamp_now() - t_entry + 0 * eps + 0 * rot);
+    Tally t;
+    __shared__ AppendLds s_app;
+    __shared__ unsigned s_hub_base;
+#ifdef PSN_PROBE_APPEND
+    if (threadIdx.x == 0) s_app.probe = do_relabel ? g.stamps : nullptr;
+#endif
+    HubTurn hub{};
+    if (hub0 >= 0) hub = hub_fetch(g, hub0);  // decided below
+    int hub_state = hub0 >= 0 ? 1 : 0;  // 1: fetched, 2: dealt with
+    for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
+        if (base != (int)blockIdx.x * span) fetch(base);
+        bool act[kVpt];
         unsigned hub_segs = 0, hub_base = 0;  // the hub's slots ride on the sweep's own slot atomic
         if (hub_state == 1) { hub_decide(g, hub, do_relabel, eps, rot, t); hub_segs = hub.act ? hub.nseg : 0u; }
 #pragma unroll
@@ -770,7 +777,7 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, i
 // refine(eps) starts from an eps-optimal pseudoflow: every residual arc whose reduced
 // cost is below -eps is saturated.  Four consecutive arcs per thread; only the thread of
 // arc a writes cap[a] and cap[rev[a]] (the reverse has reduced cost > eps and is left alone).
-__global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) {
+__device__ __forceinline__ void saturate_body(const DevGraph &g) {
     Ctrl *ct = g.ctrl;
     if (!ct->sat_on) return;
     // capacities change wholesale below: the hub segment bounds start over
@@ -945,7 +952,7 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
     for (int j = 0; j < NJ; ++j) if (cls[j] == kClsHigh) append_split(dcnt, dseg, hd[j], r0[j], r1[j], rot ^ (unsigned)hd[j]);
 }
 
-__global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
+__device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_on) return;
     const int src = k % 3, dst = (k + 1) % 3, clr = (k + 2) % 3;
@@ -1168,7 +1175,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) {
 }
 
 // dist = 0 at deficits (they seed frontier 0), "infinite" elsewhere.
-__global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) {
+__device__ __forceinline__ void gu_init_body(const DevGraph &g) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_init_on) return;
     __shared__ AppendLds s_app;
@@ -1199,7 +1206,7 @@ __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) {
 // price[v] -= eps * dist[v]; vertices that reach no deficit move by one more than the
 // largest distance handed out (any value >= the largest final distance keeps every
 // residual arc eps-optimal).
-__global__ __launch_bounds__(kBlock) void k_gu_apply(DevGraph g) {
+__device__ __forceinline__ void gu_apply_body(const DevGraph &g) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_apply_on) return;
     const i64 eps = ct->eps;
@@ -1223,7 +1230,7 @@ __global__ __launch_bounds__(kBlock) void k_gu_apply(DevGraph g) {
 }
 
 // ------------------------------------------------------------- control state machine
-__global__ void k_begin(DevGraph g) {
+__device__ __forceinline__ void begin_body(const DevGraph &g) {
     Ctrl *ct = g.ctrl;
     ct->epoch++;
     ct->sat_on = ct->gu_on = ct->gu_init_on = ct->gu_apply_on = ct->rounds_on = 0;
@@ -1242,7 +1249,7 @@ __global__ void k_begin(DevGraph g) {
         }
     }
 }
-__global__ void k_mid(DevGraph g, int n_iters) {
+__device__ __forceinline__ void mid_body(const DevGraph &g, int n_iters) {
     Ctrl *ct = g.ctrl;
     if (ct->done || ct->error) return;
     if (ct->gu_on) {
@@ -1259,7 +1266,7 @@ __global__ void k_mid(DevGraph g, int n_iters) {
     }
     for (int j = 0; j < 4; ++j) ct->list_cnt[0][j] = 0;
 }
-__global__ void k_end(DevGraph g, int n_rounds) {
+__device__ __forceinline__ void end_body(const DevGraph &g, int n_rounds) {
     Ctrl *ct = g.ctrl;
     if (ct->done || ct->error || !ct->rounds_on) return;
     const unsigned *c = ct->list_cnt[n_rounds & 1];
@@ -1539,6 +1546,37 @@ __global__ __launch_bounds__(kBlock) void k_settle_sources(DevGraph g, long long
 }
 __global__ __launch_bounds__(kBlock) void k_scatter_supply(long long count, const int *vtx, const i64 *val, i64 *supply) {
     for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock) supply[vtx[i]] = val[i];
+}
+
+
+// ------------------------------------------------------------------ kernel entry points
+// Every stage of the replay comes in two forms: one network handed over by value, and a group
+// of networks in lockstep (blockIdx.y picks the network from a table in device memory; the
+// networks share nothing, each follows its own control block, and one that has finished or
+// is waiting for another stage returns at once).  The group form divides the number of
+// launches per network by the group size, which is what bounds a batch of small networks.
+__global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) { push_body(g, k); }
+__global__ __launch_bounds__(kBlock) void k_push_group(const DevGraph *__restrict__ gs, int k) { push_body(gs[blockIdx.y], k); }
+__global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, int do_relabel) { relabel_compact_body(g, k, do_relabel); }
+__global__ __launch_bounds__(kBlock) void k_relabel_compact_group(const DevGraph *__restrict__ gs, int k, int do_relabel) { relabel_compact_body(gs[blockIdx.y], k, do_relabel); }
+__global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) { saturate_body(g); }
+__global__ __launch_bounds__(kBlock) void k_saturate_group(const DevGraph *__restrict__ gs) { saturate_body(gs[blockIdx.y]); }
+__global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) { gu_expand_body(g, k); }
+__global__ __launch_bounds__(kBlock, 4) void k_gu_expand_group(const DevGraph *__restrict__ gs, int k) { gu_expand_body(gs[blockIdx.y], k); }
+__global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) { gu_init_body(g); }
+__global__ __launch_bounds__(kBlock) void k_gu_init_group(const DevGraph *__restrict__ gs) { gu_init_body(gs[blockIdx.y]); }
+__global__ __launch_bounds__(kBlock) void k_gu_apply(DevGraph g) { gu_apply_body(g); }
+__global__ __launch_bounds__(kBlock) void k_gu_apply_group(const DevGraph *__restrict__ gs) { gu_apply_body(gs[blockIdx.y]); }
+__global__ void k_begin(DevGraph g) { begin_body(g); }
+__global__ void k_begin_group(const DevGraph *__restrict__ gs) { begin_body(gs[blockIdx.y]); }
+__global__ void k_mid(DevGraph g, int n_iters) { mid_body(g, n_iters); }
+__global__ void k_mid_group(const DevGraph *__restrict__ gs, int n_iters) { mid_body(gs[blockIdx.y], n_iters); }
+__global__ void k_end(DevGraph g, int n_rounds) { end_body(g, n_rounds); }
+__global__ void k_end_group(const DevGraph *__restrict__ gs, int n_rounds) { end_body(gs[blockIdx.y], n_rounds); }
+// done / error of every network of a group, side by side for one read-back per replay
+__global__ void k_group_status(const DevGraph *gs, int count, int *status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { const Ctrl *ct = gs[i].ctrl; status[2 * i] = ct->done; status[2 * i + 1] = ct->error; }
 }
 
 }  // namespace psn

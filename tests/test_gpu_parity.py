@@ -273,6 +273,65 @@ def test_batch_of_independent_networks_matches_oracle():
         s.close()
 
 
+def test_lockstep_group_of_unlike_networks(monkeypatch):
+    """psn_solve_batch solves contexts that share a device and configuration in lockstep (one
+    launch per stage for the whole group).  Members of very different size and shape, one of them
+    infeasible, one with nothing to route: every member gets its own optimum and certificate or
+    its own error; a warm re-solve of the group after capacity changes equals cold solves; and
+    group sizes 1 (no grouping), 3 (uneven split) and the default agree."""
+    from poseidon_amd import batch
+    rng = np.random.default_rng(77)
+    graphs = [synth.build_graph(synth.make_cluster(1, 5)),                       # 1 000 machines, ~1 M residual arcs
+              synth.build_graph(synth.make_cluster(0, 3)),
+              random_graph(rng, 60, 400, neg=True),
+              synth.graph_from_arcs(3, [0, 1], [1, 2], [2, 2], [1, 1], [0, 0, 0]),  # nothing to route
+              random_graph(rng, 500, 6000, maxcap=50, maxcost=4000),
+              synth.graph_from_arcs(2, [0], [1], [5], [7], [3, -3]),
+              synth.build_graph(synth.make_cluster(0, 9, 30, 500))]
+    want = []
+    for g in graphs:
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        assert rc == 0
+        want.append(tc)
+    solvers = []
+    for g in graphs:
+        s = pa.Solver()
+        s.upload_csr(g.n, g.row_off, g.head, g.cap, g.cost, g.rev, g.supply)
+        solvers.append(s)
+    bad = synth.graph_from_arcs(3, [0], [1], [1], [1], [0, -1, 1])             # supply that cannot leave
+    sb = pa.Solver()
+    sb.upload_csr(bad.n, bad.row_off, bad.head, bad.cap, bad.cost, bad.rev, bad.supply)
+    for cap in ("1", "3", None):
+        if cap is None:
+            monkeypatch.delenv("PSN_BATCH_GROUP", raising=False)
+        else:
+            monkeypatch.setenv("PSN_BATCH_GROUP", cap)
+        res = batch.solve_batch(solvers, workers=2)
+        assert [r.total_cost for r in res] == want, cap
+        for s, g, r in zip(solvers, graphs, res):
+            assert capi.check(g, s.residual(), s.prices())[:2] == (0, r.total_cost)
+            assert capi.check_eps(g, s.residual(), s.prices(), 1) == 0
+    # one infeasible member: the call reports it, the other members are solved all the same
+    with pytest.raises(_lib.PsnError) as ei:
+        batch.solve_batch(solvers[:3] + [sb] + solvers[3:], workers=1)
+    assert ei.value.code == _lib.PSN_EINFEASIBLE
+    for s, g, w in zip(solvers, graphs, want):
+        assert capi.check(g, s.residual(), s.prices())[:2] == (0, w)
+    # warm group solve after capacity changes on two members
+    for i in (0, 4):
+        g = graphs[i]
+        fwd = np.nonzero(g.cap > 0)[0]
+        idx = rng.choice(fwd, 20, replace=False)
+        g.cap[idx] += 1
+        solvers[i].update_caps(idx, g.cap[idx])
+        rc, want[i], _, _, _ = capi.cost_scaling(g)
+        assert rc == 0
+    res = batch.solve_batch(solvers, warm_start=True, workers=2)
+    assert [r.total_cost for r in res] == want
+    for s in solvers + [sb]:
+        s.close()
+
+
 def test_cost_model_rejects_a_layout_it_cannot_price():
     """psn_eval_costs pairs every class row with the machine rows; arc bases that do not line
     up with the uploaded network are refused instead of pricing the wrong arcs."""

@@ -67,6 +67,9 @@ for ep, k in ((6, 5), (7, 9)):
               f"begin p50 {np.percentile(bg[hs], 50):.2f} p90 {np.percentile(bg[hs], 90):.2f} max {bg[hs].max():.2f}; span {(b[ep, sr, 1] - t0) / 100.0:.2f}")
         order = np.argsort(-lw * hs)[:8]
         print("     longest-lived waves", order, np.round(lw[order], 2), "begin", np.round(bg[order], 2))
+ctrl_cyc = np.array([b[ep, 17 + 2 * k, 3] for ep in range(EP) for k in range(12) if valid[ep, 17 + 2 * k]])
+if len(ctrl_cyc):
+    print("  relabel: kernel entry -> control words read, cycles: mean %.0f p50 %.0f p90 %.0f" % (ctrl_cyc.mean(), np.percentile(ctrl_cyc, 50), np.percentile(ctrl_cyc, 90)))
 push = np.array(push)
 print("push launches", len(push), " relabel launches", len(rel))
 for lo, hi in ((0, 64), (64, 1024), (1024, 4096), (4096, 1 << 30)):
