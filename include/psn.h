@@ -171,8 +171,8 @@ int psn_solve(psn_ctx *ctx, uint32_t flags, psn_result *out);
 
 /* Solve `count` independent networks, one per context (each uploaded and priced
  * beforehand, all contexts distinct).  Contexts on one device with the same solver
- * configuration are solved in lockstep groups of up to 64 (environment PSN_BATCH_GROUP:
- * 1..128; 1 = one at a time): every stage of the solve is one launch for the whole group,
+ * configuration are solved in lockstep groups of up to 128 (environment PSN_BATCH_GROUP:
+ * 1..256; 1 = one at a time): every stage of the solve is one launch for the whole group,
  * which is what bounds many small networks; the networks share nothing and each stops
  * when it is done.  Groups are spread over `workers` host threads (0 -> 4), each driving
  * one stream.  out[i] receives the result of ctxs[i] (solve_ms of a group member is the

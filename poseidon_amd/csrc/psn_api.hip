@@ -735,7 +735,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
 // G small networks costs the launches of one.  Members must live on one device and share the
 // solver configuration; everything runs on the first member's stream.
 namespace {
-constexpr int kMaxGroup = 128;
+constexpr int kMaxGroup = 256;
 
 int group_enqueue_replay(const std::vector<psn_ctx *> &m, const DevGraph *d_graphs, int *d_status, hipStream_t s, int *launches_out) {
     const unsigned G = (unsigned)m.size();
@@ -745,6 +745,12 @@ int group_enqueue_replay(const std::vector<psn_ctx *> &m, const DevGraph *d_grap
         gv1 = std::max(gv1, std::min(kGrid, (c->g.n + kBlock - 1) / kBlock));
         gs = std::max<int>(gs, (int)std::min<long long>(kGrid, (c->m2 + kBlock * 16 - 1) / (kBlock * 16)));
     }
+    // Arc sweeps of a group: the networks bring the parallelism, so each gets only its share of a
+    // launch that fills the chip a few times over (a workgroup that finds nothing to do still
+    // costs its start-up, and a big group would start tens of thousands of them).
+    int target = 2048;
+    if (const char *ev = std::getenv("PSN_GROUP_BLOCKS")) target = std::max(256, atoi(ev));
+    gs = std::max(16, std::min(gs, (target + (int)G - 1) / (int)G));
     const int rounds = m[0]->rounds;
 #define LG(kern, grid, ...) do { hipLaunchKernelGGL(kern, dim3(grid, G), dim3(kBlock), 0, s, d_graphs, ##__VA_ARGS__); ++launches; } while (0)
     hipLaunchKernelGGL(k_begin_group, dim3(1, G), dim3(1), 0, s, d_graphs); ++launches;
@@ -860,7 +866,7 @@ int psn_solve_batch(psn_ctx *const *ctxs, int32_t count, uint32_t flags, int32_t
     if (workers <= 0) workers = 4;
     // Contexts that can share a replay sequence (same device, same solver configuration, graph
     // replay on) are solved in lockstep groups; the groups are spread over the worker threads.
-    int group_cap = 64;
+    int group_cap = 128;
     if (const char *ev = std::getenv("PSN_BATCH_GROUP")) group_cap = std::max(1, std::min(kMaxGroup, atoi(ev)));
     std::vector<std::vector<int32_t>> groups;
     {

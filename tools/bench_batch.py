@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graphs", type=int, default=256)
     ap.add_argument("--config", type=int, default=1)
-    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--workers", type=int, default=4)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--check", type=int, default=4, help="graphs per rank checked against the CPU oracle")
     args = ap.parse_args()
@@ -51,18 +51,26 @@ def main():
     P = clusters[0].layout.n_tasks
     place = torch.empty((len(mine), P), dtype=torch.int32, device="cuda")
 
+    parts = {"price": 0.0, "solve": 0.0, "extract": 0.0, "gather": 0.0}
+
     def step():
+        t = time.perf_counter()
         for s, cl, net in zip(solvers, clusters, nets):
             s.eval_costs(cl, net)
+        t1 = time.perf_counter(); parts["price"] += t1 - t
         res = batch.solve_batch(solvers, workers=args.workers)
+        t2 = time.perf_counter(); parts["solve"] += t2 - t1
         for i, s in enumerate(solvers):
             s.placements_into(place[i].data_ptr())
+        t3 = time.perf_counter(); parts["extract"] += t3 - t2
         allp = batch.all_gather_placements(place, args.graphs, world, rank)
+        parts["gather"] += time.perf_counter() - t3
         return res, allp
 
     step()
     torch.cuda.synchronize()
     if dist: dist.barrier()
+    for k in parts: parts[k] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res, allp = step()
@@ -81,7 +89,7 @@ def main():
         m = nets[0].m
         print(json.dumps({"metric": "batched MCMF scheduling solves", "graphs": args.graphs, "n_gpus": world, "workers_per_gpu": args.workers,
                           "graphs_per_s": round(args.graphs * args.steps / el, 2), "arcs_per_s": round(m * args.graphs * args.steps / el, 1),
-                          "ms_per_batch": round(el / args.steps * 1e3, 2), "mean_single_solve_ms": round(float(np.mean([r.solve_ms for r in res])), 2),
+                          "ms_per_batch": round(el / args.steps * 1e3, 2), "ms_per_batch_parts": {k: round(v / args.steps * 1e3, 1) for k, v in parts.items()}, "mean_single_solve_ms": round(float(np.mean([r.solve_ms for r in res])), 2),
                           "config": f"psn-synth-v1 config {args.config}, seed = graph id + 1, m = {m} forward arcs per graph",
                           "upload_s_not_timed": round(upload_s, 2), "placed_total": int((allp >= 0).sum().item()),
                           "cost_checksum": int(sum(costs) % (1 << 61)), "oracle_checked_per_rank": min(args.check, len(mine))}), flush=True)
