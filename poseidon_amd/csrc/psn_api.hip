@@ -695,6 +695,9 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     const long long max_replays = 200000;
     long long replays = 0;
     int status = PSN_OK;
+    const bool dbg_phases = std::getenv("PSN_DEBUG_SOLVE") != nullptr;
+    std::string phase_log;
+    int last_shift = -1; long long phase_replays = 0;
     for (;;) {
         if (c->gexec) {
             HIPCHK(c, hipGraphLaunch(c->gexec, s));
@@ -714,6 +717,11 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
             }
         }
         c->kt_used = 0;
+        if (dbg_phases) {
+            if (c->h_ctrl->eps_shift != last_shift && last_shift >= 0) { phase_log += " " + std::to_string(last_shift) + ":" + std::to_string(phase_replays + 1); phase_replays = 0; }
+            else ++phase_replays;
+            last_shift = c->h_ctrl->eps_shift;
+        }
         if (c->h_ctrl->error) { status = c->h_ctrl->error == PSN_EINFEASIBLE_DEV ? PSN_EINFEASIBLE : PSN_EDEVICE; break; }
         if (c->h_ctrl->done) break;
         if (replays >= max_replays) { status = PSN_ELIMIT; break; }
@@ -726,6 +734,12 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     solve_report(c, out, status, h_cost, h_tally, replays, c->launches_per_replay, ms);
+    if (std::getenv("PSN_DEBUG_SOLVE"))
+        fprintf(stderr, "psn_solve: %s first shift %d (max violation %lld) refines %d replays %lld rounds %llu gus %llu gu_iters %llu pushes %llu relabels %llu %.2f ms\n",
+                warm ? "warm" : "cold", ceil_log2(std::max<i64>(1, warm ? h_scalar[1] : h_scalar[2] * g.scale)) - c->cfg.alpha_log2, (long long)h_scalar[1], out->refines, replays,
+                (unsigned long long)out->rounds, (unsigned long long)out->global_updates, (unsigned long long)out->gu_iterations, (unsigned long long)out->pushes,
+                (unsigned long long)out->relabels, ms);
+    if (dbg_phases) fprintf(stderr, "   replays per phase (shift:replays)%s %d:%lld\n", phase_log.c_str(), last_shift, phase_replays);
     if (status != PSN_OK) return fail(c, status, "solve did not converge");
     return PSN_OK;
 }
