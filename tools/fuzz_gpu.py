@@ -6,6 +6,8 @@ cold several times (the push order is timing-dependent, the optimum is not), the
 warm-started.
 
   python tools/fuzz_gpu.py [seconds] [seed]
+  python tools/fuzz_gpu.py [seconds] [seed] groups     lockstep groups (psn_solve_batch) of 2..12 random networks,
+                                                       infeasible ones among them, cold and then warm
 """
 import os
 import sys
@@ -65,9 +67,62 @@ def cluster(rng):
     return synth.build_graph(cl)
 
 
+def groups(budget, rng):
+    from poseidon_amd import batch
+    t_end = time.time() + budget
+    t_say = time.time()
+    count = {"groups": 0, "members": 0, "infeasible": 0, "warm": 0}
+    pool = [pa.Solver() for _ in range(12)]
+    while time.time() < t_end:
+        if time.time() - t_say > 30:
+            print("  ...", count, flush=True)
+            t_say = time.time()
+        k = int(rng.integers(2, 13))
+        gs, want = [], []
+        for i in range(k):
+            kind = rng.choice(["generic", "hubby", "cluster"], p=[0.5, 0.3, 0.2])
+            g = {"generic": generic, "hubby": hubby, "cluster": cluster}[kind](rng)
+            rc, tc, _, _ = capi.ssp(g)
+            gs.append(g); want.append(tc if rc == 0 else None)
+            pool[i].upload_csr(g.n, g.row_off, g.head, g.cap, g.cost, g.rev, g.supply)
+        for warm in (False, True):
+            if warm:  # perturb capacities of the feasible members
+                for i, g in enumerate(gs):
+                    if want[i] is None or not (g.cap > 0).any():
+                        continue
+                    live = np.nonzero(g.cap > 0)[0]
+                    idx = rng.choice(live, size=min(int(rng.integers(1, 20)), live.shape[0]), replace=False)
+                    newcap = rng.integers(0, 8, idx.shape[0]).astype(np.int32)
+                    pool[i].update_caps(idx.astype(np.int64), newcap)
+                    g.cap[idx] = newcap
+                    rc, tc, _, _ = capi.ssp(g)
+                    want[i] = tc if rc == 0 else None
+            try:
+                res = batch.solve_batch(pool[:k], warm_start=warm, workers=int(rng.integers(1, 4)))
+                assert all(w is not None for w in want), "an infeasible member went unreported"
+            except pa.PsnError as e:
+                assert e.code == -4 and any(w is None for w in want), (e, want)
+                res = None
+            for i, g in enumerate(gs):
+                if want[i] is None:
+                    count["infeasible"] += 1
+                    continue
+                crc, ctc, _ = capi.check(g, pool[i].residual(), pool[i].prices())
+                assert crc == 0 and ctc == want[i], (i, crc, ctc, want[i])
+                if res is not None:
+                    assert res[i].total_cost == want[i]
+            count["warm" if warm else "groups"] += 1
+            count["members"] += k
+    for s in pool:
+        s.close()
+    print("fuzz groups ok:", count, flush=True)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    if "groups" in sys.argv[3:]:
+        return groups(budget, rng)
     t_end = time.time() + budget
     count = {"generic": 0, "hubby": 0, "cluster": 0, "warm": 0}
     t_say = time.time()
