@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, help="psn-synth-v1 config id (2 = 10k machines / 100k pods)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-graphs", type=int, default=64,
+                    help="what-if networks (config 1) per GPU for the batched-throughput figure reported beside the headline; 0: skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +137,52 @@ def main():
         all_costs = [res[-1].total_cost]
         placed_all = int((place >= 0).sum().item())
 
+    # ---- beside the headline: the batch of independent what-if networks (1 000 machines / 10 000 pods each),
+    # a fixed number per GPU, solved in lockstep groups; placements all-gathered like the headline's
+    batch_out = None
+    if args.batch_graphs > 0:
+        from poseidon_amd import batch as pbatch
+        B = args.batch_graphs
+        bcl, bnet, bsol = [], [], []
+        for b in range(B):
+            c1 = pa.synth_cluster(1, 1 + rank * B + b)
+            n1 = pa.build_network(c1)
+            s1 = pa.Solver(device=local_rank)
+            s1.upload(n1)
+            bcl.append(c1); bnet.append(n1); bsol.append(s1)
+        P1 = bcl[0].layout.n_tasks
+        bplace = torch.empty((B, P1), dtype=torch.int32, device="cuda")
+        bgath = torch.empty((world * B, P1), dtype=torch.int32, device=cdev) if world > 1 else None
+
+        def bstep():
+            for s1, c1, n1 in zip(bsol, bcl, bnet):
+                s1.eval_costs(c1, n1)
+            rs = pbatch.solve_batch(bsol)
+            for i, s1 in enumerate(bsol):
+                s1.placements_into(bplace[i].data_ptr())
+            if world > 1:
+                dist.all_gather_into_tensor(bgath, bplace if backend == "nccl" else bplace.cpu())
+            return rs
+
+        bstep()
+        fence()
+        tb = time.perf_counter()
+        bsteps = 2
+        for _ in range(bsteps):
+            brs = bstep()
+        fence()
+        bel = time.perf_counter() - tb
+        if world > 1:
+            t = torch.tensor([bel], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bel = float(t.item())
+        batch_out = {"workload": f"psn-synth-v1 config 1 ({bnet[0].m} forward arcs each), {B} networks per GPU, lockstep groups",
+                     "graphs": B * world, "graphs_per_s": round(B * world * bsteps / bel, 1),
+                     "arcs_per_s": round(bnet[0].m * B * world * bsteps / bel, 1), "ms_per_batch": round(bel / bsteps * 1e3, 2),
+                     "cost_checksum_rank0": int(sum(r_.total_cost for r_ in brs) % (1 << 61))}
+        for s1 in bsol:
+            s1.close()
+
     ms_per_step = elapsed / args.steps * 1e3
     arcs_per_s = net.m * world * args.steps / elapsed
     r = res[-1]
@@ -193,7 +241,7 @@ def main():
                          "gu_iterations": r.gu_iterations, "global_updates": r.global_updates, "refines": r.refines,
                          "launches": r.launches},
             "solve_algorithmic_GBps": round(r.algorithmic_bytes / (solve_ms * 1e-3) / 1e9, 1),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "what_if_batch": batch_out,
         }
         print(json.dumps(out), flush=True)
     solver.close()

@@ -95,6 +95,12 @@ constexpr unsigned kStampExpandMin = PSN_STAMP_EXPAND_MIN;
 #define PSN_STAMP_EXPAND_MAX 4000000000u
 #endif
 constexpr unsigned kStampExpandMax = PSN_STAMP_EXPAND_MAX;
+#ifndef PSN_STAMP_PUSH_MIN
+#define PSN_STAMP_PUSH_MIN 200u  // wave-item counts of the push sweeps that leave per-wave records
+#endif
+#ifndef PSN_STAMP_PUSH_MAX
+#define PSN_STAMP_PUSH_MAX 3000u
+#endif
 #ifndef PSN_STAMP_PUSH
 #define PSN_STAMP_PUSH 1  // 0: the push sweep leaves the per-wave records to the expand sweep
 #endif
@@ -648,7 +654,7 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyRounds]++;
     tally_flush<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds>(g, t);
 #ifdef PSN_STAMPS
-    if (PSN_STAMP_PUSH && g.stamps && nseg >= 200 && nseg < 3000 && nlow == 0 && lane_id() == 0) {
+    if (PSN_STAMP_PUSH && g.stamps && nseg >= PSN_STAMP_PUSH_MIN && nseg < PSN_STAMP_PUSH_MAX && (nlow == 0 || PSN_STAMP_PUSH_MIN >= 3000u) && lane_id() == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long tk4 = stamp_now();
         unsigned long long *o = g.stamps + (size_t)wave * 16;
