@@ -124,18 +124,16 @@ int enqueue_replay(psn_ctx *c, hipStream_t s) {
         mark(cls, false);                                                 \
         ++launches;                                                       \
     } while (0)
-    hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, g); ++launches;
+    hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, g, c->rounds); ++launches;
     L(PSN_KT_SATURATE, k_saturate, gs, g);
     L(PSN_KT_OTHER, k_gu_init, gv, g);
     for (int k = 0; k < kGuIters; ++k) L(PSN_KT_GU_EXPAND, k_gu_expand, gs, g, k);
-    hipLaunchKernelGGL(k_mid, dim3(1), dim3(1), 0, s, g, kGuIters); ++launches;
-    L(PSN_KT_OTHER, k_gu_apply, gv1, g);
+    L(PSN_KT_OTHER, k_gu_apply, gv1, g, kGuIters);
     L(PSN_KT_RELABEL, k_relabel_compact, gv, g, 0, 0);
     for (int k = 0; k < c->rounds; ++k) {
         L(PSN_KT_PUSH, k_push, gs, g, k);
         L(PSN_KT_RELABEL, k_relabel_compact, gv, g, k, 1);
     }
-    hipLaunchKernelGGL(k_end, dim3(1), dim3(1), 0, s, g, c->rounds); ++launches;
 #undef L
     c->launches_per_replay = launches;
     return PSN_OK;
@@ -724,6 +722,11 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
         }
         if (c->h_ctrl->error) { status = c->h_ctrl->error == PSN_EINFEASIBLE_DEV ? PSN_EINFEASIBLE : PSN_EDEVICE; break; }
         if (c->h_ctrl->done) break;
+        {   // the rounds of this replay emptied the work list at epsilon 1: solved (what the next k_begin would find)
+            const Ctrl &h = *c->h_ctrl;
+            const unsigned *lc = h.list_cnt[c->rounds & 1];
+            if (h.rounds_on && lc[kClsLow] + lc[kClsSeg] == 0 && h.eps_shift == 0) break;
+        }
         if (replays >= max_replays) { status = PSN_ELIMIT; break; }
     }
     unsigned long long h_tally[kTallyN];
@@ -767,19 +770,17 @@ int group_enqueue_replay(const std::vector<psn_ctx *> &m, const DevGraph *d_grap
     gs = std::max(16, std::min(gs, (target + (int)G - 1) / (int)G));
     const int rounds = m[0]->rounds;
 #define LG(kern, grid, ...) do { hipLaunchKernelGGL(kern, dim3(grid, G), dim3(kBlock), 0, s, d_graphs, ##__VA_ARGS__); ++launches; } while (0)
-    hipLaunchKernelGGL(k_begin_group, dim3(1, G), dim3(1), 0, s, d_graphs); ++launches;
+    hipLaunchKernelGGL(k_begin_group, dim3(1, G), dim3(1), 0, s, d_graphs, rounds); ++launches;
     LG(k_saturate_group, gs);
     LG(k_gu_init_group, gv);
     for (int k = 0; k < kGuIters; ++k) LG(k_gu_expand_group, gs, k);
-    hipLaunchKernelGGL(k_mid_group, dim3(1, G), dim3(1), 0, s, d_graphs, kGuIters); ++launches;
-    LG(k_gu_apply_group, gv1);
+    LG(k_gu_apply_group, gv1, kGuIters);
     LG(k_relabel_compact_group, gv, 0, 0);
     for (int k = 0; k < rounds; ++k) {
         LG(k_push_group, gs, k);
         LG(k_relabel_compact_group, gv, k, 1);
     }
-    hipLaunchKernelGGL(k_end_group, dim3(1, G), dim3(1), 0, s, d_graphs, rounds); ++launches;
-    hipLaunchKernelGGL(k_group_status, dim3(1), dim3(kMaxGroup), 0, s, d_graphs, (int)G, d_status); ++launches;
+    hipLaunchKernelGGL(k_group_status, dim3(1), dim3(kMaxGroup), 0, s, d_graphs, (int)G, rounds, d_status); ++launches;
 #undef LG
     *launches_out = launches;
     return PSN_OK;
@@ -832,7 +833,7 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
     t_b = now();
     GCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     group_enqueue_replay(m, d_graphs, d_status, s, &launches);
-    GCHK(hipStreamEndCapture(s, &graph));
+    GCHK(hipStreamEndCapture(s, &graph));  // ends the capture whether or not it yields a graph
     GCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
     t_c = now();
     const long long max_replays = 200000;

@@ -29,14 +29,14 @@ constexpr int PSN_EINFEASIBLE_DEV = -4;
 enum { kTallyScans = 0, kTallyPushes, kTallyRelabels, kTallyVisits, kTallyGuScans, kTallyGuRelax,
        kTallySat, kTallyRounds, kTallyGuIters, kTallyN };
 
-// Device-resident loop control.  Single-thread kernels (k_begin / k_mid / k_end) are the
+// Device-resident loop control.  k_begin (one thread) and the first thread of k_gu_apply are the
 // only writers of the flags; sweep kernels read them and return at once when their
 // stage is off, which is what lets a fixed hipGraph be replayed until `done`.
 struct Ctrl {
     i64 eps;
     int eps_shift, alpha_log2;
     int need_sat, need_gu, gu_active;
-    int sat_on, gu_on, gu_init_on, gu_apply_on, rounds_on;
+    int sat_on, gu_on, gu_init_on, rounds_on;
     int done, error;
     unsigned epoch, gu_stamp_base;
     unsigned list_cnt[2][4];
@@ -88,20 +88,16 @@ __global__ void k_relabel_compact(DevGraph g, int k, int do_relabel);
 __global__ void k_saturate(DevGraph g);
 __global__ void k_gu_init(DevGraph g);
 __global__ void k_gu_expand(DevGraph g, int k);
-__global__ void k_gu_apply(DevGraph g);
-__global__ void k_begin(DevGraph g);
-__global__ void k_mid(DevGraph g, int n_iters);
-__global__ void k_end(DevGraph g, int n_rounds);
+__global__ void k_gu_apply(DevGraph g, int n_iters);
+__global__ void k_begin(DevGraph g, int n_rounds);
 __global__ void k_push_group(const DevGraph *gs, int k);
 __global__ void k_relabel_compact_group(const DevGraph *gs, int k, int do_relabel);
 __global__ void k_saturate_group(const DevGraph *gs);
 __global__ void k_gu_init_group(const DevGraph *gs);
 __global__ void k_gu_expand_group(const DevGraph *gs, int k);
-__global__ void k_gu_apply_group(const DevGraph *gs);
-__global__ void k_begin_group(const DevGraph *gs);
-__global__ void k_mid_group(const DevGraph *gs, int n_iters);
-__global__ void k_end_group(const DevGraph *gs, int n_rounds);
-__global__ void k_group_status(const DevGraph *gs, int count, int *status);
+__global__ void k_gu_apply_group(const DevGraph *gs, int n_iters);
+__global__ void k_begin_group(const DevGraph *gs, int n_rounds);
+__global__ void k_group_status(const DevGraph *gs, int count, int n_rounds, int *status);
 __global__ void k_reset(DevGraph g, const i64 *supply, int keep_flow);
 __global__ void k_mirror(DevGraph g, const i64 *supply, int recompute_excess);
 __global__ void k_excess_from_flow(DevGraph g);

@@ -1212,9 +1212,26 @@ __device__ __forceinline__ void gu_init_body(const DevGraph &g) {
 // price[v] -= eps * dist[v]; vertices that reach no deficit move by one more than the
 // largest distance handed out (any value >= the largest final distance keeps every
 // residual arc eps-optimal).
-__device__ __forceinline__ void gu_apply_body(const DevGraph &g) {
+__device__ __forceinline__ void gu_apply_body(const DevGraph &g, int n_iters) {
     Ctrl *ct = g.ctrl;
-    if (!ct->gu_apply_on) return;
+    // Control step between the expansions and the rounds: every workgroup works the decision out
+    // from words this kernel does not write; the first thread of the launch records it.
+    if (ct->done || ct->error) return;
+    bool apply = false, rounds = true, give_up = false;
+    if (ct->gu_on) {
+        const unsigned *c = ct->fr_cnt[n_iters % 3];
+        if (c[kClsLow] + c[kClsSeg] == 0) apply = true;
+        // the 16-bit sweep stamps are about to repeat: give this update up (leaving the prices
+        // alone is always valid) and go on with push/relabel rounds
+        else if (ct->gu_stamp_base + 2u * kGuIters > 60000u) give_up = true;
+        else rounds = false;  // the frontier is not empty yet: the update goes on in the next replay
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (apply || give_up) { ct->gu_active = 0; ct->need_gu = 0; }
+        if (rounds) ct->rounds_on = 1;
+        for (int j = 0; j < 4; ++j) ct->list_cnt[0][j] = 0;
+    }
+    if (!apply) return;
     const i64 eps = ct->eps;
     __shared__ i64 s_dmax[kBlock / 64];
     i64 dm = 0;
@@ -1236,10 +1253,33 @@ __device__ __forceinline__ void gu_apply_body(const DevGraph &g) {
 }
 
 // ------------------------------------------------------------- control state machine
-__device__ __forceinline__ void begin_body(const DevGraph &g) {
+// The rounds of a replay end with the work list the last relabel sweep built: empty means the
+// phase is over (the solve too, at epsilon 1), else a global update comes first next time.
+// Evaluated at the start of the next replay; the host (or k_group_status) reads the same words
+// to see that the solve is over, so no replay is spent on finding out.
+__device__ __forceinline__ bool rounds_closed_solve(const Ctrl *ct, int n_rounds) {
+    if (ct->done || ct->error || !ct->rounds_on) return false;
+    const unsigned *c = ct->list_cnt[n_rounds & 1];
+    return c[kClsLow] + c[kClsSeg] == 0 && ct->eps_shift == 0;
+}
+__device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
     Ctrl *ct = g.ctrl;
+    if (!ct->done && !ct->error && ct->rounds_on) {  // close the rounds of the previous replay
+        const unsigned *c = ct->list_cnt[n_rounds & 1];
+        if (c[kClsLow] + c[kClsSeg] == 0) {
+            if (ct->eps_shift == 0) {
+                ct->done = 1;
+            } else {
+                ct->eps_shift = ct->eps_shift > ct->alpha_log2 ? ct->eps_shift - ct->alpha_log2 : 0;
+                ct->eps = (i64)1 << ct->eps_shift;
+                ct->need_sat = 1;
+            }
+        } else {
+            ct->need_gu = 1;
+        }
+    }
     ct->epoch++;
-    ct->sat_on = ct->gu_on = ct->gu_init_on = ct->gu_apply_on = ct->rounds_on = 0;
+    ct->sat_on = ct->gu_on = ct->gu_init_on = ct->rounds_on = 0;
     if (ct->done || ct->error) return;
     if (ct->need_sat) { ct->sat_on = 1; ct->need_sat = 0; ct->need_gu = 1; ct->tally_refines++; }
     if (ct->need_gu) {
@@ -1253,36 +1293,6 @@ __device__ __forceinline__ void begin_body(const DevGraph &g) {
         } else {
             ct->gu_stamp_base += kGuIters;  // sweep stamps stay unique within one update
         }
-    }
-}
-__device__ __forceinline__ void mid_body(const DevGraph &g, int n_iters) {
-    Ctrl *ct = g.ctrl;
-    if (ct->done || ct->error) return;
-    if (ct->gu_on) {
-        const unsigned *c = ct->fr_cnt[n_iters % 3];
-        if (c[kClsLow] + c[kClsSeg] == 0) {
-            ct->gu_apply_on = 1; ct->gu_active = 0; ct->need_gu = 0; ct->rounds_on = 1;
-        } else if (ct->gu_stamp_base + 2u * kGuIters > 60000u) {
-            // the 16-bit sweep stamps are about to repeat: give this update up (leaving the prices
-            // alone is always valid) and go on with push/relabel rounds
-            ct->gu_active = 0; ct->need_gu = 0; ct->rounds_on = 1;
-        }
-    } else {
-        ct->rounds_on = 1;
-    }
-    for (int j = 0; j < 4; ++j) ct->list_cnt[0][j] = 0;
-}
-__device__ __forceinline__ void end_body(const DevGraph &g, int n_rounds) {
-    Ctrl *ct = g.ctrl;
-    if (ct->done || ct->error || !ct->rounds_on) return;
-    const unsigned *c = ct->list_cnt[n_rounds & 1];
-    if (c[kClsLow] + c[kClsSeg] == 0) {
-        if (ct->eps_shift == 0) { ct->done = 1; return; }
-        ct->eps_shift = ct->eps_shift > ct->alpha_log2 ? ct->eps_shift - ct->alpha_log2 : 0;
-        ct->eps = (i64)1 << ct->eps_shift;
-        ct->need_sat = 1;
-    } else {
-        ct->need_gu = 1;
     }
 }
 
@@ -1571,18 +1581,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) { gu
 __global__ __launch_bounds__(kBlock, 4) void k_gu_expand_group(const DevGraph *__restrict__ gs, int k) { gu_expand_body(gs[blockIdx.y], k); }
 __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) { gu_init_body(g); }
 __global__ __launch_bounds__(kBlock) void k_gu_init_group(const DevGraph *__restrict__ gs) { gu_init_body(gs[blockIdx.y]); }
-__global__ __launch_bounds__(kBlock) void k_gu_apply(DevGraph g) { gu_apply_body(g); }
-__global__ __launch_bounds__(kBlock) void k_gu_apply_group(const DevGraph *__restrict__ gs) { gu_apply_body(gs[blockIdx.y]); }
-__global__ void k_begin(DevGraph g) { begin_body(g); }
-__global__ void k_begin_group(const DevGraph *__restrict__ gs) { begin_body(gs[blockIdx.y]); }
-__global__ void k_mid(DevGraph g, int n_iters) { mid_body(g, n_iters); }
-__global__ void k_mid_group(const DevGraph *__restrict__ gs, int n_iters) { mid_body(gs[blockIdx.y], n_iters); }
-__global__ void k_end(DevGraph g, int n_rounds) { end_body(g, n_rounds); }
-__global__ void k_end_group(const DevGraph *__restrict__ gs, int n_rounds) { end_body(gs[blockIdx.y], n_rounds); }
+__global__ __launch_bounds__(kBlock) void k_gu_apply(DevGraph g, int n_iters) { gu_apply_body(g, n_iters); }
+__global__ __launch_bounds__(kBlock) void k_gu_apply_group(const DevGraph *__restrict__ gs, int n_iters) { gu_apply_body(gs[blockIdx.y], n_iters); }
+__global__ void k_begin(DevGraph g, int n_rounds) { begin_body(g, n_rounds); }
+__global__ void k_begin_group(const DevGraph *__restrict__ gs, int n_rounds) { begin_body(gs[blockIdx.y], n_rounds); }
 // done / error of every network of a group, side by side for one read-back per replay
-__global__ void k_group_status(const DevGraph *gs, int count, int *status) {
+__global__ void k_group_status(const DevGraph *gs, int count, int n_rounds, int *status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) { const Ctrl *ct = gs[i].ctrl; status[2 * i] = ct->done; status[2 * i + 1] = ct->error; }
+    if (i < count) { const Ctrl *ct = gs[i].ctrl; status[2 * i] = ct->done || rounds_closed_solve(ct, n_rounds); status[2 * i + 1] = ct->error; }
 }
 
 }  // namespace psn
