@@ -1015,6 +1015,27 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
 #endif
         STAMP(ts_i1);
         STAMP_ADD(acc_item, ts_i0, ts_i1);
+        if (r1 - r0 <= 64u) {
+            // Short rows (a job's aggregator: some fifty tasks) go one arc per lane: eight arcs per
+            // lane would leave seven lanes doing all the atomics and lookups of the row one after
+            // the other, and such a row then costs more than a full 576-arc step.
+            const unsigned a = r0 + (unsigned)lane;
+            const bool in = a < r1;
+            const int rc = in ? g.rcap[a] : 0;
+            int hd1[1] = {in ? g.head[a] : 0}, hub1[1] = {-1};
+            const int cs1 = in ? g.cost[a] : 0;
+            t.c[kTallyGuScans] += in;
+            const bool on = rc > 0;
+            const i64 p1 = on ? g.price[hd1[0]] : 0, d1 = on ? ld_dist(g, hd1[0]) : 0;
+            if (on) hub1[0] = g.hub_of[hd1[0]];
+            i64 nd1[1] = {kDistInf};
+            if (on) { const i64 l = arc_len(-(i64)cs1 * S + p1 - pv, sh); if (dv + l < d1) nd1[0] = dv + l; }
+#ifdef PSN_STAMPS
+            ++n_steps;
+#endif
+            gu_commit_batch<1>(g, q, dcnt, dlow, dseg, s_hmin, hd1, hub1, nd1, stamp, rot, wmax, t);
+            continue;
+        }
         for (unsigned h = r0; h < r1; h += kStep) {
             STAMP(ts_s0);
             const unsigned a0 = h + lane * 8, lim8 = min(r1, h + 512), at = h + 512 + lane, limt = min(r1, h + kStep);
@@ -1142,32 +1163,50 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     STAMP(ts_lane_items);
     __syncthreads();  // hub minima of the whole workgroup are in LDS
     STAMP(ts_barrier);
-    if (my_hub_vertex >= 0 && s_hmin[threadIdx.x] < kDistInf) {
+    // The end of the sweep is a handful of independent read-modify-writes (hub distance, the two
+    // queue counters, the largest-distance slot, the work counters).  Their first halves are all
+    // issued before any result is used, so the wave waits one round trip for them, not five.
+    const bool hub_cand = my_hub_vertex >= 0 && s_hmin[threadIdx.x] < kDistInf;
+    const i64 hub_nd = hub_cand ? s_hmin[threadIdx.x] : kDistInf;
+    // one check per hub and workgroup, against a fresh value (most workgroups arrive after
+    // the first few have lowered the hub's distance and can skip the same-address atomic)
+    const i64 hub_seen = hub_cand ? __hip_atomic_load(&g.dist[my_hub_vertex], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the staged queue entries are in LDS
+    unsigned base_low = 0, base_seg = 0;
+    if (lane == 0 && q.nlow) base_low = aadd32(&dcnt[kClsLow], q.nlow);
+    if (lane == 0 && q.nseg) base_seg = aadd32(&dcnt[kClsSeg], q.nseg);
+    i64 *dmax_slot = g.dmax_part + wave;
+    unsigned long long *tslot = g.tally + (size_t)wave * kTallyN;  // this wave's work counters
+    i64 dmax_seen = 0;
+    unsigned long long t_scans = 0, t_relax = 0, t_iters = 0;
+    if (lane == 0) { dmax_seen = *dmax_slot; t_scans = tslot[kTallyGuScans]; t_relax = tslot[kTallyGuRelax]; t_iters = tslot[kTallyGuIters]; }
+    // second halves
+    i64 hub_gain = 0;
+    if (hub_cand && hub_nd < dist_of(hub_seen)) {
         const int u = my_hub_vertex;
-        const i64 nd = s_hmin[threadIdx.x];
-        // one check per hub and workgroup, against a fresh value (most workgroups arrive after
-        // the first few have lowered the hub's distance and can skip the same-address atomic)
-        if (nd < dist_of(__hip_atomic_load(&g.dist[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            const i64 old = amin64(&g.dist[u], dist_pack(nd, stamp));
-            if (nd < dist_of(old)) {
-                t.c[kTallyGuRelax]++;
-                if (nd > wmax) wmax = nd;
-                if ((unsigned)(old & 0xFFFF) != stamp)  // first to lower it in this sweep; hubs are always split vertices
-                    append_split(dcnt, dseg, u, my_hub_row0, my_hub_row1, rot ^ (unsigned)u);
-            }
+        const i64 old = amin64(&g.dist[u], dist_pack(hub_nd, stamp));
+        if (hub_nd < dist_of(old)) {
+            t.c[kTallyGuRelax]++;
+            hub_gain = hub_nd;
+            if ((unsigned)(old & 0xFFFF) != stamp)  // first to lower it in this sweep; hubs are always split vertices
+                append_split(dcnt, dseg, u, my_hub_row0, my_hub_row1, rot ^ (unsigned)u);
         }
     }
     STAMP(ts_hubs);
-    waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
-    waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);
+    base_low = __shfl(base_low, 0);
+    base_seg = __shfl(base_seg, 0);
+    for (unsigned i = lane; i < q.nlow; i += 64) dlow[base_low + i] = q.low[i];
+    for (unsigned i = lane; i < q.nseg; i += 64) dseg[base_seg + i] = q.seg[i];
     // Largest distance handed out: kept per wave slot (no shared counter: thousands of waves
     // raising one word serialise at the memory side); k_gu_apply folds the slots.
-    wmax = wave_max(wmax);
-    if (lane == 0 && wmax > 0) {
-        i64 *slot = g.dmax_part + wave;
-        if (wmax > *slot) *slot = wmax;
+    wmax = wave_max(wmax > hub_gain ? wmax : hub_gain);
+    const unsigned n_scans = wave_sum_u32(t.c[kTallyGuScans]), n_relax = wave_sum_u32(t.c[kTallyGuRelax]), n_iters = wave_sum_u32(t.c[kTallyGuIters]);
+    if (lane == 0) {
+        if (wmax > dmax_seen) *dmax_slot = wmax;
+        if (n_scans) tslot[kTallyGuScans] = t_scans + n_scans;
+        if (n_relax) tslot[kTallyGuRelax] = t_relax + n_relax;
+        if (n_iters) tslot[kTallyGuIters] = t_iters + n_iters;
     }
-    tally_flush<kTallyGuScans, kTallyGuRelax, kTallyGuIters>(g, t);
 #ifdef PSN_STAMPS
     if (g.stamps && nseg >= kStampExpandMin && nseg < kStampExpandMax && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);

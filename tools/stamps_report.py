@@ -26,6 +26,22 @@ print("  100 MHz clock: wave begins (us since first)", np.percentile((b[:, 12] -
 life_rt = (b[:, 15] - b[:, 12]) / 100.0
 life_cy = (b[:, 5] - b[:, 0])
 print("  wave life us: mean", life_rt.mean(), " cycles per us (s_memtime / 100 MHz clock):", (life_cy / np.maximum(life_rt, 0.01)).mean())
+# imbalance: by XCD (workgroups are dealt round-robin over the 8 XCDs), by items per wave, by position in the grid
+if len(b) == 4096:
+    widx = np.arange(4096)
+    xcd = (widx // 4) % 8
+    print("  wave life us by XCD (mean / max):", " ".join(f"{life_rt[xcd == x].mean():.1f}/{life_rt[xcd == x].max():.1f}" for x in range(8)))
+    for n_it in np.unique(b[:, 6]):
+        sel = b[:, 6] == n_it
+        print(f"  waves with {n_it} items: {int(sel.sum())}, life us mean {life_rt[sel].mean():.1f} p90 {np.percentile(life_rt[sel], 90):.1f} max {life_rt[sel].max():.1f}")
+    q = [life_rt[i * 512:(i + 1) * 512].mean() for i in range(8)]
+    print("  wave life us by eighth of the grid (mean):", " ".join(f"{x:.1f}" for x in q))
+    for nm, col in (("steps", 7), ("item+dist+price cycles", 8), ("arc rows cycles", 9), ("gathers cycles", 10), ("commit cycles", 11)):
+        print(f"  {nm} per wave by eighth of the grid (mean):", " ".join(f"{b[i * 512:(i + 1) * 512, col].mean():.0f}" for i in range(8)))
+    tail = b[:, 5] - b[:, 1]
+    print("  cycles after the wave items (lane items, barrier, hubs, flush) by eighth:", " ".join(f"{tail[i * 512:(i + 1) * 512].mean():.0f}" for i in range(8)))
+    per_item = life_rt / np.maximum(b[:, 6], 1)
+    print("  life per item us: p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(per_item, [10, 50, 90, 100])))
 names = ["begin", "wave items done", "lane items done", "after barrier", "hubs flushed", "end"]
 print("  cycles since the wave's own begin (the counters of different XCDs are not aligned):")
 for i, nm in enumerate(names):
