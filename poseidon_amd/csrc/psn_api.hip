@@ -10,6 +10,7 @@
 #include <string>
 #include <utility>
 #include <atomic>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -269,22 +270,46 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     int64_t ssum = 0;
     for (int32_t v = 0; v < n; ++v) ssum += supply[v];
     if (ssum != 0) return fail(c, PSN_EINFEASIBLE, "supplies do not sum to zero");
-    std::vector<int> tail((size_t)m2);
-    for (int32_t v = 0; v < n; ++v)
-        for (int64_t a = row_off[v]; a < row_off[v + 1]; ++a) tail[(size_t)a] = v;
+    std::unique_ptr<int[]> tail(new int[(size_t)std::max<int64_t>(m2, 1)]);  // filled below, no need to clear 40 MB first
     int64_t max_abs = 0;
-    for (int64_t a = 0; a < m2; ++a) {
-        const int32_t r = rev[a];
-        if (head[a] < 0 || head[a] >= n) return fail(c, PSN_EINVAL, "head out of range");
-        if (r < 0 || r >= m2 || rev[r] != a) return fail(c, PSN_EINVAL, "rev is not an involution");
-        if (r == a && (head[a] != tail[(size_t)a] || cap[a] != 0 || cost[a] != 0))
-            return fail(c, PSN_EINVAL, "an arc may pair with itself only as an unused placeholder (self-loop, cap 0, cost 0)");
-        if (head[r] != tail[(size_t)a]) return fail(c, PSN_EINVAL, "rev does not point at the reverse arc");
-        if (cost[r] != -cost[a]) return fail(c, PSN_EINVAL, "cost[rev[a]] != -cost[a]");
-        if (cap[a] < 0) return fail(c, PSN_EINVAL, "negative capacity");
-        if ((int64_t)cap[a] + cap[r] > INT32_MAX) return fail(c, PSN_EOVERFLOW, "capacity pair overflows int32");
-        const int64_t ac = cost[a] < 0 ? -(int64_t)cost[a] : cost[a];
-        if (ac > max_abs) max_abs = ac;
+    {
+        // Arc checks are independent: large networks are checked by a few threads, each over a
+        // range of vertices (tails) and the arcs of those rows; the error reported is the one at
+        // the lowest arc index, as a single pass would find it.
+        struct Found { int64_t arc = INT64_MAX; int code = PSN_OK; const char *what = nullptr; int64_t max_abs = 0; };
+        const int nthreads = m2 >= (1 << 20) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+        std::vector<Found> found((size_t)nthreads);
+        auto check_range = [&](int t) {
+            Found &f = found[(size_t)t];
+            const int32_t v0 = (int32_t)((int64_t)n * t / nthreads), v1 = (int32_t)((int64_t)n * (t + 1) / nthreads);
+            for (int32_t v = v0; v < v1; ++v)
+                for (int64_t a = row_off[v]; a < row_off[v + 1]; ++a) tail[(size_t)a] = v;
+            auto bad = [&](int64_t a, int code, const char *what) { f.arc = a; f.code = code; f.what = what; };
+            for (int64_t a = row_off[v0]; a < row_off[v1]; ++a) {
+                const int32_t r = rev[a];
+                if (head[a] < 0 || head[a] >= n) { bad(a, PSN_EINVAL, "head out of range"); return; }
+                if (r < 0 || r >= m2 || rev[r] != a) { bad(a, PSN_EINVAL, "rev is not an involution"); return; }
+                if (r == a && (head[a] != tail[(size_t)a] || cap[a] != 0 || cost[a] != 0)) {
+                    bad(a, PSN_EINVAL, "an arc may pair with itself only as an unused placeholder (self-loop, cap 0, cost 0)"); return;
+                }
+                if (head[r] != tail[(size_t)a]) { bad(a, PSN_EINVAL, "rev does not point at the reverse arc"); return; }
+                if (cost[r] != -cost[a]) { bad(a, PSN_EINVAL, "cost[rev[a]] != -cost[a]"); return; }
+                if (cap[a] < 0) { bad(a, PSN_EINVAL, "negative capacity"); return; }
+                if ((int64_t)cap[a] + cap[r] > INT32_MAX) { bad(a, PSN_EOVERFLOW, "capacity pair overflows int32"); return; }
+                const int64_t ac = cost[a] < 0 ? -(int64_t)cost[a] : cost[a];
+                if (ac > f.max_abs) f.max_abs = ac;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(check_range, t);
+        check_range(0);
+        for (auto &th : pool) th.join();
+        const Found *first = nullptr;
+        for (const Found &f : found) {
+            if (f.code != PSN_OK && (!first || f.arc < first->arc)) first = &f;
+            max_abs = std::max(max_abs, f.max_abs);
+        }
+        if (first) return fail(c, first->code, first->what);
     }
     {   // price magnitudes stay below ~ 8 * n * max|cost| * (n+1)
         const long double bound = 8.0L * (long double)n * (long double)(max_abs + 1) * (long double)(n + 1);
@@ -368,7 +393,7 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     HIPCHK(c, hipMemcpyAsync(d_hub_row0, hub_row0.data(), sizeof(unsigned) * (size_t)kMaxHubs, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_hub_seg0, hub_seg0.data(), sizeof(int) * (size_t)kMaxHubs, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_seg1_of, seg1_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(d_tail, tail.data(), sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_tail, tail.get(), sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_head, head, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_cost, cost, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_rev, rev, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
