@@ -261,6 +261,9 @@ void psn_destroy(psn_ctx *c) {
 int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, const int32_t *head, const int32_t *cap,
                    const int32_t *cost, const int32_t *rev, const int64_t *supply) {
     if (!c) return PSN_EINVAL;
+    const bool dbg_up = std::getenv("PSN_DEBUG_UPLOAD") != nullptr;
+    auto now_up = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tu0 = now_up();
     if (n <= 0 || n >= kMaxVertices || m2 < 0 || m2 >= (int64_t)0x7FFFFFF0 || !row_off || !supply || (m2 > 0 && (!head || !cap || !cost || !rev)))
         return fail(c, PSN_EINVAL, "null or out-of-range argument");
     // ---- validate on the host: a malformed graph must never reach a kernel
@@ -275,7 +278,9 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     {
         // Arc checks are independent: large networks are checked by a few threads, each over a
         // range of vertices (tails) and the arcs of those rows; the error reported is the one at
-        // the lowest arc index, as a single pass would find it.
+        // the lowest arc index, as a single pass would find it.  (The checks read the far end of
+        // every pair, four random cache lines per arc: on a host short of memory bandwidth the
+        // threads gain little; PSN_DEBUG_UPLOAD=1 prints what each part of the upload took.)
         struct Found { int64_t arc = INT64_MAX; int code = PSN_OK; const char *what = nullptr; int64_t max_abs = 0; };
         const int nthreads = m2 >= (1 << 20) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
         std::vector<Found> found((size_t)nthreads);
@@ -315,9 +320,11 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
         const long double bound = 8.0L * (long double)n * (long double)(max_abs + 1) * (long double)(n + 1);
         if (bound > 4.0e18L) return fail(c, PSN_EOVERFLOW, "n^2 * max|cost| too large for int64 prices");
     }
+    const double tu1 = now_up();
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_graph_buffers(c);
+    const double tu2 = now_up();
     c->n = n;
     c->m2 = m2;
     // ---- classify vertices by degree
@@ -385,6 +392,7 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     g.row = d_row; g.head = d_head; g.cost = c->d_cost; g.rev = d_rev; g.tail = d_tail; g.ocap = c->d_ocap; g.cls = d_cls;
     g.hub_of = d_hub_of; g.hub_vertex = d_hub_vertex; g.nhubs = nhubs;
     g.hub_row0 = d_hub_row0; g.hub_seg0 = d_hub_seg0; g.seg1_of = d_seg1_of; g.n_hub_segs = n_hub_segs;
+    const double tu3 = now_up();
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(d_row, row.data(), sizeof(unsigned) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_cls, cls.data(), (size_t)n, hipMemcpyHostToDevice, s));
@@ -402,7 +410,9 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     HIPCHK(c, hipMemcpyAsync(c->d_supply, supply, sizeof(i64) * (size_t)n, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemsetAsync(g.price, 0, sizeof(i64) * (size_t)n, s));
     HIPCHK(c, hipStreamSynchronize(s));  // host staging vectors die at return
+    const double tu4 = now_up();
     if ((rc = build_graph(c)) != PSN_OK) { free_graph_buffers(c); return rc; }
+    if (dbg_up) fprintf(stderr, "psn_upload_csr: checks %.1f free %.1f classify+alloc %.1f copies %.1f graph capture %.1f ms\n", tu1 - tu0, tu2 - tu1, tu3 - tu2, tu4 - tu3, now_up() - tu4);
     c->uploaded = true;
     return PSN_OK;
 }

@@ -755,31 +755,40 @@ int64_t psn_svc_schedule(psn_svc *s) {
         if (s->slot_used[(size_t)t]) members[(size_t)s->slot_task[(size_t)t]->cls].push_back(t);
     i64 placed = 0;
     std::vector<int32_t> final_place((size_t)s->P, -1);
+    std::vector<int> units(s->machines.size(), 0);  // units of the class on each machine; cleared through `touched`
+    std::vector<int> touched, rest;
+    std::vector<char> done;
     for (int e = 0; e < s->E; ++e) {
-        std::unordered_map<int, int> units;
+        const std::vector<int> &mem = members[(size_t)e];
         i64 total = 0;
-        for (int t : members[(size_t)e]) if (place[(size_t)t] >= 0) { ++units[place[(size_t)t]]; ++total; }
+        touched.clear();
+        for (int t : mem) {
+            const int m = place[(size_t)t];
+            if (m < 0) continue;
+            if ((size_t)m >= units.size()) return s->fail(PSN_EDEVICE, "placement names a machine that does not exist");
+            if (units[(size_t)m]++ == 0) touched.push_back(m);
+            ++total;
+        }
         if (!total) continue;
-        std::vector<char> done(members[(size_t)e].size(), 0);
-        for (size_t i = 0; i < members[(size_t)e].size(); ++i) {  // keep what can be kept
-            const Task &tk = *s->slot_task[(size_t)members[(size_t)e][i]];
+        done.assign(mem.size(), 0);
+        for (size_t i = 0; i < mem.size(); ++i) {  // keep what can be kept
+            const Task &tk = *s->slot_task[(size_t)mem[i]];
             if (tk.machine < 0 || (size_t)tk.machine >= s->machines.size() || s->machines[(size_t)tk.machine].gen != tk.machine_gen) continue;
-            auto it = units.find(tk.machine);
-            if (it == units.end() || it->second == 0) continue;
-            --it->second; --total;
-            final_place[(size_t)members[(size_t)e][i]] = tk.machine;
+            if (units[(size_t)tk.machine] == 0) continue;
+            --units[(size_t)tk.machine]; --total;
+            final_place[(size_t)mem[i]] = tk.machine;
             done[i] = 1;
         }
         // the rest of the units, machine by machine, to the tasks the solver routed, then to any other
-        std::vector<int> rest;
-        for (auto &kv : units) for (int c = 0; c < kv.second; ++c) rest.push_back(kv.first);
-        std::sort(rest.begin(), rest.end());
+        std::sort(touched.begin(), touched.end());
+        rest.clear();
+        for (int m : touched) { for (int c = 0; c < units[(size_t)m]; ++c) rest.push_back(m); units[(size_t)m] = 0; }
         size_t ri = 0;
         for (int pass = 0; pass < 2 && ri < rest.size(); ++pass)
-            for (size_t i = 0; i < members[(size_t)e].size() && ri < rest.size(); ++i) {
+            for (size_t i = 0; i < mem.size() && ri < rest.size(); ++i) {
                 if (done[i]) continue;
-                if (pass == 0 && place[(size_t)members[(size_t)e][i]] < 0) continue;
-                final_place[(size_t)members[(size_t)e][i]] = rest[ri++];
+                if (pass == 0 && place[(size_t)mem[i]] < 0) continue;
+                final_place[(size_t)mem[i]] = rest[ri++];
                 done[i] = 1;
             }
     }
