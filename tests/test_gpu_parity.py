@@ -157,6 +157,52 @@ def test_error_codes(solver):
     assert lib.psn_last_error(solver._ctx)
 
 
+def test_malformed_networks_are_rejected_before_any_solve(solver):
+    """The arcs are checked on the device after the copy, indices range-checked before use: every
+    kind of damage is refused with its own message, the context is left without a network, and a
+    sound upload afterwards works."""
+    lib = pa.load_library()
+    good = synth.build_graph(synth.make_cluster(0, 4, 20, 150))
+    m2 = good.head.shape[0]
+    cand = np.nonzero(good.rev > np.arange(m2))[0]  # its pair lies further on: the damaged arc is met first
+    fwd = int(cand[cand.shape[0] // 2])
+
+    def damaged(field, at, value):
+        arr = {k: getattr(good, k).copy() for k in ("head", "cap", "cost", "rev")}
+        arr[field][at] = value
+        return arr
+
+    cases = [("head", fwd, good.n, _lib.PSN_EINVAL, "head out of range"),
+             ("head", fwd, -1, _lib.PSN_EINVAL, "head out of range"),
+             ("rev", fwd, m2 + 5, _lib.PSN_EINVAL, "involution"),
+             ("rev", fwd, -7, _lib.PSN_EINVAL, "involution"),
+             ("rev", fwd, 2**31 - 1, _lib.PSN_EINVAL, "involution"),
+             ("rev", fwd, fwd, _lib.PSN_EINVAL, "placeholder"),
+             ("cost", fwd, int(good.cost[fwd]) + 1, _lib.PSN_EINVAL, "cost[rev[a]]"),
+             ("cap", fwd, -3, _lib.PSN_EINVAL, "negative capacity"),
+             ("cap", fwd, 2**31 - 1, None, None)]
+    for field, at, value, code, text in cases:
+        arr = damaged(field, at, value)
+        if code is None:  # a capacity pair that overflows needs both sides large
+            arr["cap"][good.rev[at]] = 2**31 - 1
+            code, text = _lib.PSN_EOVERFLOW, "overflows"
+        with pytest.raises(pa.PsnError) as ei:
+            solver.upload_csr(good.n, good.row_off, arr["head"], arr["cap"], arr["cost"], arr["rev"], good.supply)
+        assert ei.value.code == code, (field, value, ei.value.code)
+        assert text in lib.psn_last_error(solver._ctx).decode(), (field, value, lib.psn_last_error(solver._ctx))
+        with pytest.raises(pa.PsnError) as ei:  # nothing is resident after a rejected upload
+            solver.solve()
+        assert ei.value.code == _lib.PSN_ESTATE
+    # the lowest damaged arc is the one reported
+    arr = damaged("cap", m2 - 1, -1)
+    arr["head"][0] = good.n
+    with pytest.raises(pa.PsnError):
+        solver.upload_csr(good.n, good.row_off, arr["head"], arr["cap"], arr["cost"], arr["rev"], good.supply)
+    assert "head out of range" in lib.psn_last_error(solver._ctx).decode()
+    rc, tc, _, _, _ = capi.cost_scaling(good)
+    assert rc == 0 and solve_and_certify(solver, good).total_cost == tc
+
+
 @pytest.mark.parametrize("cfg,seed", [(0, 1), (0, 2), (0, 3), (1, 1), (1, 2)])
 def test_synthetic_clusters_vs_golden_and_oracle(solver, cfg, seed):
     cl = pa.synth_cluster(cfg, seed)
