@@ -21,6 +21,7 @@
 #include <tuple>
 #include <unordered_map>
 #include <unordered_set>
+#include <thread>
 #include <vector>
 
 #include "../../include/psn.h"
@@ -347,15 +348,27 @@ struct psn_svc {
             head[(size_t)a] = to; cap[(size_t)a] = cp; cost[(size_t)a] = cs; rev[(size_t)a] = (int32_t)r;
             head[(size_t)r] = from; cap[(size_t)r] = 0; cost[(size_t)r] = -cs; rev[(size_t)r] = (int32_t)a;
         };
-        for (int e = 0; e < E; ++e) {
-            const i64 r0 = row_off[(size_t)(v_ec + e)];
-            for (int i = 0; i < room_e[(size_t)e]; ++i) { head[(size_t)(r0 + i)] = v_ec + e; rev[(size_t)(r0 + i)] = (int32_t)(r0 + i); }
-            const i64 base = r0 + room_e[(size_t)e];
-            ec_arc_base[(size_t)e] = base;
-            for (i64 m = 0; m < N; ++m)
-                for (i64 k = 0; k < K; ++k) pair_up(base + m * K + k, row_off[(size_t)(1 + m)] + (i64)e * K + k, (int)(1 + m), v_ec + e, 0, 0);
-            if ((size_t)e < classes.size()) classes[(size_t)e].pool = spare_class_pool(e);
+        // the class x machine x slot block is most of the network; classes write disjoint arcs, so
+        // a large block is filled by a few threads
+        auto fill_classes = [&](int e0, int e1) {
+            for (int e = e0; e < e1; ++e) {
+                const i64 r0 = row_off[(size_t)(v_ec + e)];
+                for (int i = 0; i < room_e[(size_t)e]; ++i) { head[(size_t)(r0 + i)] = v_ec + e; rev[(size_t)(r0 + i)] = (int32_t)(r0 + i); }
+                const i64 base = r0 + room_e[(size_t)e];
+                ec_arc_base[(size_t)e] = base;
+                for (i64 m = 0; m < N; ++m)
+                    for (i64 k = 0; k < K; ++k) pair_up(base + m * K + k, row_off[(size_t)(1 + m)] + (i64)e * K + k, (int)(1 + m), v_ec + e, 0, 0);
+            }
+        };
+        {
+            const int nthreads = (i64)E * N * K >= (1 << 20) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nthreads; ++t) pool.emplace_back(fill_classes, (int)((i64)E * t / nthreads), (int)((i64)E * (t + 1) / nthreads));
+            fill_classes(0, E / nthreads);
+            for (auto &th : pool) th.join();
         }
+        for (int e = 0; e < E; ++e)
+            if ((size_t)e < classes.size()) classes[(size_t)e].pool = spare_class_pool(e);
         for (int j = 0; j < J; ++j) {
             const i64 r0 = row_off[(size_t)(v_un + j)];
             for (int i = 0; i < room_j[(size_t)j]; ++i) { head[(size_t)(r0 + i)] = v_un + j; rev[(size_t)(r0 + i)] = (int32_t)(r0 + i); }
