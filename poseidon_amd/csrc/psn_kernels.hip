@@ -991,7 +991,6 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
     const int my_hub_vertex = hub_vertex_of_thread(g);
-    const unsigned my_hub_row0 = my_hub_vertex >= 0 ? g.row[my_hub_vertex] : 0u, my_hub_row1 = my_hub_vertex >= 0 ? g.row[my_hub_vertex + 1] : 0u;
     i64 wmax = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyGuIters]++;
     const int4 *segl = g.fr_seg[src];
@@ -1189,7 +1188,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
             t.c[kTallyGuRelax]++;
             hub_gain = hub_nd;
             if ((unsigned)(old & 0xFFFF) != stamp)  // first to lower it in this sweep; hubs are always split vertices
-                append_split(dcnt, dseg, u, my_hub_row0, my_hub_row1, rot ^ (unsigned)u);
+                append_split(dcnt, dseg, u, g.row[u], g.row[u + 1], rot ^ (unsigned)u);  // once per hub and sweep: not worth two registers held through the sweep
         }
     }
     STAMP(ts_hubs);
