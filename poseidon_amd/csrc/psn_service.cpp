@@ -118,6 +118,7 @@ struct psn_svc {
     std::unordered_set<int32_t> dirty_supply;
     std::vector<int32_t> new_sources;
     bool reprice = false;
+    bool settled = false;  // the last round ran to its end and nothing has been queued since
     // results
     std::vector<Delta> deltas;
     psn_svc_stats st{};
@@ -670,6 +671,16 @@ int64_t psn_svc_schedule(psn_svc *s) {
     s->deltas.clear();
     int rc;
     if (!s->laid_out || s->need_layout) { if ((rc = s->layout()) != PSN_OK) return rc; }
+    // Nothing was submitted, removed, re-priced or re-labelled since a round that ran to its end:
+    // the resident optimum still stands and there is nothing to report (Poseidon calls Schedule
+    // on a timer, /root/reference/cmd/poseidon/poseidon.go:32-72; most rounds of a quiet cluster are such).
+    if (s->settled && s->resident && !s->cfg.emit_noop && s->dirty_arcs.empty() && s->cap_updates.empty() && s->dirty_supply.empty() &&
+        s->new_sources.empty() && !s->mask_dirty && !s->reprice) {
+        s->st.last_round_warm = 1;
+        ++s->st.warm_rounds;
+        return 0;
+    }
+    s->settled = false;
     std::vector<i64> cc, cm, uc, um, rq, rm;
     psn_result res{};
     bool warm = false;
@@ -825,6 +836,7 @@ int64_t psn_svc_schedule(psn_svc *s) {
     s->st.machines_live = (i64)s->machine_by_uuid.size();
     s->st.n = s->n;
     s->st.m2 = s->m2;
+    s->settled = true;
     return (int64_t)s->deltas.size();
 }
 

@@ -59,6 +59,9 @@ def test_schedule_rounds_cold_then_warm(cfg, seed):
         assert placement_cost(cl, uids, where) == st.total_cost
         # nothing changed: the next round reports nothing
         assert s.Schedule() == [] and s.stats().total_cost == st.total_cost
+        # nothing was queued since the last round: the resident optimum stands, no solve is run
+        idle = s.stats()
+        assert idle.solve_ms == 0 and idle.last_round_warm == 1 and idle.rounds == st.rounds + 1
         nxt = int(uids.max()) + 1
         for rnd in (1, 2):
             old_uids = set(int(u) for u in uids)
