@@ -143,7 +143,9 @@ int psn_svc_add_task_stats(psn_svc *svc, uint64_t task_uid);
 int psn_svc_check(const psn_svc *svc);
 
 /* Schedule (:17): one scheduling round.  Returns the number of deltas (>= 0) or a negative
- * PSN_E* code; the deltas stay readable until the next round. */
+ * PSN_E* code; the deltas stay readable until the next round.  A round with nothing queued
+ * since the last completed one (no task, node, label or statistics RPC) returns 0 at once:
+ * the resident optimum still stands (not so with emit_noop, which reports every task). */
 int64_t psn_svc_schedule(psn_svc *svc);
 /* Copy deltas [first, first+count): task uid, change type and the 36-character resource
  * uuid of the machine (NUL-terminated, 37 bytes per delta; empty for PREEMPT). */
