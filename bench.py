@@ -8,7 +8,14 @@ network (BASELINE.json configs[2]), inputs resident in HBM before the timed regi
 
 One step = one full pass (K1 + cold solve + K5) over one network per GPU; with N > 1
 every rank solves its own independent network (seed = 1 + rank, weak scaling) and the
-placements are all-gathered over RCCL.  Rank 0 prints ONE JSON line.
+placements are all-gathered over RCCL.  Rank 0 prints ONE JSON line.  Beside the headline:
+  what_if_batch  BASELINE.json configs[4]: 256 independent 1k-machine / 10k-pod networks in
+                 total, network b on rank b mod N (strong scaling), solved in lockstep groups,
+                 placements all-gathered;
+  c3             configs[3] on one GPU: scheduler-service rounds at the 1k and 10k sizes, cold
+                 and warm after 5 % churn, with the parts of each round;
+  roofline       the dominant kernel against the HBM roofline, in both currencies;
+  cpu_baseline   the CPU cost-scaling solver on the same network, on the host cores.
 """
 from __future__ import annotations
 
@@ -55,6 +62,89 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def machine_uuid(i):
+    return f"00000000-0000-4000-8000-{i:012d}"
+
+
+def service_rounds(config_id, seed, device, churn_rounds=2):
+    """configs[3]: the cluster fed to the scheduler service RPC by RPC, one cold Schedule, then
+    rounds of 5 % churn applied in place and warm-started.  Every task is re-optimised in every
+    round (reschedule_running), so each round's optimum is that of the churned cluster built from
+    scratch; the last churned cluster is also solved cold in a fresh context for the comparison."""
+    from poseidon_amd import network
+    from poseidon_amd.firmament import ChangeType
+    cl = pa.synth_cluster(config_id, seed)
+    N, P = cl.layout.n_machines, cl.layout.n_tasks
+    task_class, task_job = cl.task_class.copy(), cl.task_job.copy()
+    used_cpu, used_mem = cl.used_cpu.copy(), cl.used_mem.copy()
+    out_mask = np.zeros(N, bool)
+    rounds = []
+
+    def part(st, wall_ms, n_deltas, moved=None):
+        d = {"wall_ms": round(wall_ms, 2), "build_ms": round(st.build_ms, 2), "upload_ms": round(st.upload_ms, 2),
+             "update_ms": round(st.update_ms, 2), "solve_ms": round(st.solve_ms, 2), "extract_ms": round(st.extract_ms, 2),
+             "warm": int(st.last_round_warm), "deltas": n_deltas, "cost": int(st.total_cost),
+             "patched_arcs": int(st.patched_arcs), "cap_updates": int(st.cap_updates), "supply_updates": int(st.supply_updates)}
+        if moved is not None:
+            d["migrated_or_preempted"] = moved
+        return d
+
+    with pa.SchedulerService(device=device, reschedule_running=True) as s:
+        for m in range(N):
+            s.NodeAdded(machine_uuid(m), int(cl.cap_cpu[m]), int(cl.cap_mem[m]))
+            s.AddNodeStats(machine_uuid(m), int(used_cpu[m]), int(used_mem[m]))
+        uids = np.arange(1, P + 1, dtype=np.int64)
+        for t in range(P):
+            e = int(task_class[t])
+            s.TaskSubmitted(int(uids[t]), f"job-{int(task_job[t]):06d}", int(cl.req_cpu[e]), int(cl.req_mem[e]))
+        t0 = time.perf_counter()
+        deltas = s.Schedule()
+        rounds.append(("cold", part(s.stats(), (time.perf_counter() - t0) * 1e3, len(deltas))))
+        allocs_before = pa.load_library().psn_debug_alloc_count()
+        nxt = P + 1
+        for rnd in range(1, churn_rounds + 1):
+            ch = network.churn_round(cl, config_id, seed, rnd)
+            for i, t in enumerate(ch.tasks_replaced):
+                s.TaskRemoved(int(uids[t]))
+                uids[t] = nxt + i
+                task_class[t], task_job[t] = ch.new_class[i], ch.new_job[i]
+                e = int(ch.new_class[i])
+                s.TaskSubmitted(int(uids[t]), f"job-{int(ch.new_job[i]):06d}", int(cl.req_cpu[e]), int(cl.req_mem[e]))
+            nxt += ch.tasks_replaced.shape[0]
+            for i, m in enumerate(ch.machines_restat):
+                if not out_mask[m]:
+                    s.AddNodeStats(machine_uuid(int(m)), int(ch.new_used_cpu[i]), int(ch.new_used_mem[i]))
+                used_cpu[m], used_mem[m] = ch.new_used_cpu[i], ch.new_used_mem[i]
+            for m in ch.machines_out:
+                if not out_mask[m]:
+                    s.NodeRemoved(machine_uuid(int(m)))
+                out_mask[m] = True
+            t0 = time.perf_counter()
+            deltas = s.Schedule()
+            moved = sum(d.type in (ChangeType.MIGRATE, ChangeType.PREEMPT) for d in deltas)
+            rounds.append((f"churn{rnd}", part(s.stats(), (time.perf_counter() - t0) * 1e3, len(deltas), moved)))
+        allocs_warm = pa.load_library().psn_debug_alloc_count() - allocs_before
+    # the last churned cluster from scratch: same optimum, and what a cold solve of it costs
+    cl2 = pa.network.Cluster(cl.layout, cl.cap_cpu, cl.cap_mem, used_cpu, used_mem, cl.req_cpu, cl.req_mem, task_class, task_job, cl.slots)
+    net2 = pa.build_network(cl2)
+    E, K = cl.layout.n_classes, cl.layout.k_slots
+    with pa.Solver(device=device) as sv:
+        sv.upload(net2)
+        sv.eval_costs(cl2, net2)
+        gone = np.nonzero(out_mask)[0]
+        if gone.shape[0]:
+            arcs = np.array([net2.row_off[1 + m] + E * K for m in gone], np.int64)  # machine -> sink
+            sv.update_caps(arcs, np.zeros(arcs.shape[0], np.int32))
+        rc = sv.solve()
+    out = {name: p for name, p in rounds}
+    out["cold_solve_of_last_churned_cluster_ms"] = round(rc.solve_ms, 2)
+    out["warm_equals_cold_cost"] = bool(rc.total_cost == rounds[-1][1]["cost"])
+    out["allocations_during_warm_rounds"] = int(allocs_warm)
+    warm_ms = float(np.mean([p["solve_ms"] for name, p in rounds[1:]]))
+    out["warm_over_cold_solve"] = round(warm_ms / max(rc.solve_ms, 1e-9), 3)
+    return out, (cl2, out_mask)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,8 +152,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, help="psn-synth-v1 config id (2 = 10k machines / 100k pods)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch-graphs", type=int, default=64,
-                    help="what-if networks (config 1) per GPU for the batched-throughput figure reported beside the headline; 0: skip")
+    ap.add_argument("--batch-graphs", type=int, default=256,
+                    help="what-if networks (config 1) IN TOTAL for the batched figure (network b on rank b mod N); 0: skip")
+    ap.add_argument("--batch-check", type=int, default=4, help="networks per rank of the batch checked against the CPU oracle")
+    ap.add_argument("--no-c3", action="store_true", help="skip the scheduler-service rounds (configs[3])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,59 +228,75 @@ def main():
     else:
         all_costs = [res[-1].total_cost]
         placed_all = int((place >= 0).sum().item())
+    solver.close()
 
     # ---- beside the headline: the batch of independent what-if networks (1 000 machines / 10 000 pods each),
-    # a fixed number per GPU, solved in lockstep groups; placements all-gathered like the headline's
+    # 256 in total, network b on rank b mod N, solved in lockstep groups; placements all-gathered into graph order
     batch_out = None
     if args.batch_graphs > 0:
         from poseidon_amd import batch as pbatch
         B = args.batch_graphs
+        mine = pbatch.shard(B, world, rank)
         bcl, bnet, bsol = [], [], []
-        for b in range(B):
-            c1 = pa.synth_cluster(1, 1 + rank * B + b)
+        for b in mine:
+            c1 = pa.synth_cluster(1, 1 + b)
             n1 = pa.build_network(c1)
             s1 = pa.Solver(device=local_rank)
             s1.upload(n1)
             bcl.append(c1); bnet.append(n1); bsol.append(s1)
-        P1 = bcl[0].layout.n_tasks
-        bplace = torch.empty((B, P1), dtype=torch.int32, device="cuda")
-        bgath = torch.empty((world * B, P1), dtype=torch.int32, device=cdev) if world > 1 else None
+        P1 = 10_000
+        m1 = bnet[0].m if bnet else 533_200
+        bplace = torch.empty((len(mine), P1), dtype=torch.int32, device="cuda")
 
         def bstep():
             for s1, c1, n1 in zip(bsol, bcl, bnet):
                 s1.eval_costs(c1, n1)
-            rs = pbatch.solve_batch(bsol)
+            rs = pbatch.solve_batch(bsol) if bsol else []
             for i, s1 in enumerate(bsol):
                 s1.placements_into(bplace[i].data_ptr())
-            if world > 1:
-                dist.all_gather_into_tensor(bgath, bplace if backend == "nccl" else bplace.cpu())
-            return rs
+            allp = pbatch.all_gather_placements(bplace if backend == "nccl" else bplace.cpu(), B, world, rank)
+            return rs, allp
 
         bstep()
         fence()
         tb = time.perf_counter()
-        bsteps = 2
+        bsteps = 3
         for _ in range(bsteps):
-            brs = bstep()
+            brs, ballp = bstep()
         fence()
         bel = time.perf_counter() - tb
         if world > 1:
             t = torch.tensor([bel], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             bel = float(t.item())
-        batch_out = {"workload": f"psn-synth-v1 config 1 ({bnet[0].m} forward arcs each), {B} networks per GPU, lockstep groups",
-                     "graphs": B * world, "graphs_per_s": round(B * world * bsteps / bel, 1),
-                     "arcs_per_s": round(bnet[0].m * B * world * bsteps / bel, 1), "ms_per_batch": round(bel / bsteps * 1e3, 2),
-                     "cost_checksum_rank0": int(sum(r_.total_cost for r_ in brs) % (1 << 61))}
+        bcosts = pbatch.all_gather_costs([r_.total_cost for r_ in brs], B, world, rank, device=cdev)
+        # the checker: some of this rank's networks against the CPU oracle (outside every timed region)
+        checked = 0
+        if args.batch_check > 0:
+            from oracle import capi, synth
+            for i in range(min(args.batch_check, len(mine))):
+                rc_, tc_, _, _, _ = capi.cost_scaling(synth.build_graph(synth.make_cluster(1, 1 + mine[i])))
+                assert rc_ == 0 and tc_ == brs[i].total_cost, (mine[i], tc_, brs[i].total_cost)
+                checked += 1
+        if world > 1:
+            t = torch.tensor([checked], dtype=torch.int64, device=cdev)
+            dist.all_reduce(t)
+            checked = int(t.item())
+        batch_out = {"workload": f"BASELINE configs[4]: {B} psn-synth-v1 config 1 networks in total ({m1} forward arcs each, seed = graph id + 1), "
+                                 f"network b on rank b mod {world}, lockstep groups, placements all-gathered",
+                     "graphs": B, "n_gpus": world, "scaling": "strong", "graphs_per_s": round(B * bsteps / bel, 1),
+                     "arcs_per_s": round(m1 * B * bsteps / bel, 1), "ms_per_batch": round(bel / bsteps * 1e3, 2),
+                     "placed_total": int((ballp >= 0).sum().item()), "cost_checksum": int(sum(bcosts) % (1 << 61)),
+                     "oracle_checked": checked}
         for s1 in bsol:
             s1.close()
 
     ms_per_step = elapsed / args.steps * 1e3
     arcs_per_s = net.m * world * args.steps / elapsed
     r = res[-1]
-    solve_ms = float(np.median([x.solve_ms for x in res]))
+    solve_all = [x.solve_ms for x in res]
+    solve_ms = float(np.median(solve_all))
 
-    out = None
     if rank == 0:
         # ---- roofline of the dominant kernel: one extra solve with HIP-event timing of every launch
         roof = None
@@ -203,28 +311,55 @@ def main():
             bytes_total = algorithmic_bytes(tr, dom)
             achieved = bytes_total / (dom_ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic("k_" + dom)
+            avg_us = dom_ms * 1e3 / dom_calls
             roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from " + str(traffic_src),
-                    "launches": dom_calls, "avg_launch_us": round(dom_ms * 1e3 / dom_calls, 2),
+                    "launches": dom_calls, "avg_launch_us": round(avg_us, 2),
                     "algorithmic_bytes_per_launch": int(bytes_total / dom_calls),
+                    # both currencies: the 20-bytes-per-arc-scan rule, and what HBM saw (PMC pass of the committed profile)
+                    "achieved_contract": round(achieved, 1),
+                    "achieved_hbm": round(traffic / (avg_us * 1e-6) / 1e9, 1) if traffic else None,
                     "kernel_ms": {k: round(v[0], 2) for k, v in kt.items()}}
+            if dom == "gu_expand":
+                # steps of split rows in which no lane saw residual capacity read the 4-byte capacity only
+                real = 20 * (tr.gu_arc_scans - tr.gu_arc_skips) + 4 * tr.gu_arc_skips
+                roof["gu_arc_skips"] = tr.gu_arc_skips
+                roof["achieved_skips_at_4B"] = round(real / (dom_ms * 1e-3) / 1e9, 1)
+        # ---- configs[3]: scheduler-service rounds, cold and warm after churn
+        c3 = None
+        if not args.no_c3 and world == 1:
+            c3 = {}
+            for cfg_id in (1, 2):
+                c3[f"config{cfg_id}"], _ = service_rounds(cfg_id, 1, local_rank)
         # ---- CPU baseline: the oracle's single-thread cost-scaling solver on the same network
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # timed on rank 0 of the single-GPU run only
             from oracle import capi, synth
+            try:
+                os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})  # one core, as a sequential solver gets
+                pinned = True
+            except (AttributeError, OSError):
+                pinned = False
+            capi.use_native_build()
             ocl = synth.make_cluster(args.config, seed)
             og = synth.build_graph(ocl)
-            times, ccost = [], None
-            for _ in range(3 if args.config >= 2 else 5):
-                rc, ccost, _, _, st = capi.cost_scaling(og)
-                times.append(st.solve_ms)
-            cpu_ms = float(np.median(times))
-            cpu = {"value": round(og.m / (cpu_ms * 1e-3), 1), "unit": "arcs/s", "cores": 1, "kind": "port",
-                   "solve_ms": round(cpu_ms, 1), "host_cores_total": os.cpu_count(), "optimal_cost": int(ccost),
+            rows = {}
+            for name, kw in capi.BASELINE_VARIANTS.items():
+                times, ccost = [], None
+                for _ in range(3 if args.config >= 2 else 5):
+                    rc, ccost, _, _, st = capi.cost_scaling(og, **kw)
+                    assert rc == 0
+                    times.append(st.solve_ms)
+                assert ccost == all_costs[0], (name, ccost, all_costs)
+                rows[name] = {"solve_ms": round(float(np.median(times)), 1), "arcs_per_s": round(og.m / (float(np.median(times)) * 1e-3), 1),
+                              "pushes": int(st.pushes), "relabels": int(st.relabels), "global_updates": int(st.global_updates)}
+            best = min(rows, key=lambda k: rows[k]["solve_ms"])
+            cpu = {"value": rows[best]["arcs_per_s"], "unit": "arcs/s", "cores": 1, "kind": "port",
+                   "solve_ms": rows[best]["solve_ms"], "variant": best, "variants": rows, "pinned_to_one_core": pinned,
+                   "host_cores_total": os.cpu_count(), "optimal_cost": int(all_costs[0]), "build": capi.build_flags(),
                    "sample": f"full psn-synth-v1 config {args.config} seed {seed} network, single-thread cost-scaling "
-                             f"push-relabel (oracle/psn_oracle.c), median of {len(times)} solves"}
-            assert ccost == all_costs[0], (ccost, all_costs)
+                             f"push-relabel (oracle/psn_oracle.c), median of 3 solves per variant, the faster variant reported"}
         out = {
             "metric": "MCMF scheduling solve throughput (forward arcs of the input network per second; K1 pricing + cold "
                       "cost-scaling solve + placement extraction, 10k-node/100k-pod graph)",
@@ -234,17 +369,17 @@ def main():
             "config": {"workload": f"psn-synth-v1 config {args.config}: {cl.layout.n_machines} machines / {P} pods, "
                                    f"n={net.n} vertices, m={net.m} forward arcs, one network per GPU (seed = 1 + rank)",
                        "graphs_per_step": world, "alpha": 16, "rounds_per_global_update": 12},
-            "solve_ms": round(solve_ms, 3), "optimal_cost": all_costs, "tasks_placed": placed_all,
+            "solve_ms": round(solve_ms, 3), "solve_ms_min": round(min(solve_all), 3), "solve_ms_max": round(max(solve_all), 3),
+            "optimal_cost": all_costs, "tasks_placed": placed_all,
             "upload_s_not_timed": round(upload_s, 4),
-            "counters": {"arc_scans": r.arc_scans, "gu_arc_scans": r.gu_arc_scans, "sat_arc_scans": r.sat_arc_scans,
+            "counters": {"arc_scans": r.arc_scans, "gu_arc_scans": r.gu_arc_scans, "gu_arc_skips": r.gu_arc_skips, "sat_arc_scans": r.sat_arc_scans,
                          "pushes": r.pushes, "relabels": r.relabels, "vertex_visits": r.vertex_visits, "rounds": r.rounds,
                          "gu_iterations": r.gu_iterations, "global_updates": r.global_updates, "refines": r.refines,
                          "launches": r.launches},
             "solve_algorithmic_GBps": round(r.algorithmic_bytes / (solve_ms * 1e-3) / 1e9, 1),
-            "roofline": roof, "cpu_baseline": cpu, "what_if_batch": batch_out,
+            "roofline": roof, "cpu_baseline": cpu, "what_if_batch": batch_out, "c3": c3,
         }
         print(json.dumps(out), flush=True)
-    solver.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

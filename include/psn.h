@@ -43,7 +43,7 @@ typedef struct psn_ctx psn_ctx;
 
 typedef struct psn_config {
     int32_t device;          /* HIP device ordinal */
-    int32_t alpha_log2;      /* epsilon divisor per refine = 2^alpha_log2 (0 -> default 4) */
+    int32_t alpha_log2;      /* epsilon divisor per refine, alpha = 2^alpha_log2; 0 -> default alpha_log2 = 4, i.e. alpha = 16 */
     int32_t rounds_per_batch;/* push/relabel rounds between global price updates (0 -> default) */
     int32_t flags;           /* PSN_CFG_* */
 } psn_config;
@@ -78,6 +78,8 @@ typedef struct psn_result {
     uint64_t global_updates;
     uint64_t launches;       /* kernel launches issued (graph nodes included) */
     double solve_ms;         /* device time, first refine kernel -> cost readback */
+    uint64_t gu_arc_skips;   /* of gu_arc_scans: arcs in 576-arc steps of split rows where no lane saw residual
+                              * capacity, so only the 4-byte capacity word was read (not head, cost, distance) */
 } psn_result;
 
 #define PSN_WARM_START 1u    /* psn_solve: keep prices and flow from the previous solve */
@@ -174,8 +176,13 @@ int psn_solve(psn_ctx *ctx, uint32_t flags, psn_result *out);
  * configuration are solved in lockstep groups of up to 128 (environment PSN_BATCH_GROUP:
  * 1..256; 1 = one at a time): every stage of the solve is one launch for the whole group,
  * which is what bounds many small networks; the networks share nothing and each stops
- * when it is done.  Groups are spread over `workers` host threads (0 -> 4), each driving
- * one stream.  out[i] receives the result of ctxs[i] (solve_ms of a group member is the
+ * when it is done.  Fewer than four contexts that could share a group are solved one after
+ * the other instead (a group's launches carry every member's idle stages).  The contexts may
+ * live on several GPUs of the node: grouping is per device, and the groups are spread over
+ * `workers` host threads (0 -> 4, or two per device when that is more; never fewer than one
+ * per device), each driving one stream, so the devices work side by side.  A group's replay
+ * graph is kept by its first context and reused while the same contexts, in the same order,
+ * keep their uploads.  out[i] receives the result of ctxs[i] (solve_ms of a group member is the
  * group's time); the first error code is returned, the other solves still run.  This is
  * the batch of what-if scheduling rounds: each is the same Schedule solve
  * (/root/reference/pkg/firmament/firmament_scheduler.proto:17) on its own cluster state. */
@@ -196,6 +203,22 @@ int psn_get_placements(psn_ctx *ctx, const psn_layout *layout, int32_t *task_to_
 /* Same as psn_get_placements but into caller-owned device memory (int32[P]) on this
  * context's GPU, e.g. the send buffer of an all-gather; returns after the copy is done. */
 int psn_get_placements_device(psn_ctx *ctx, const psn_layout *layout, void *dst_device);
+
+/* Placements of `count` solved contexts into one buffer, row i (int32, `stride` entries apart,
+ * layouts[i].n_tasks of them written) for ctxs[i].  The contexts may live on different GPUs of
+ * the node: every context runs its extraction on its own device and stream, then the rows are
+ * copied to host memory (dst_device < 0) or into memory of GPU dst_device (peer copies over
+ * xGMI for contexts on other GPUs).  With psn_solve_batch this is the whole multi-GPU batch of
+ * what-if rounds from one process: each row is what a Schedule reply would carry as deltas
+ * (/root/reference/pkg/firmament/scheduling_delta.proto:25-41) for its cluster state. */
+int psn_gather_placements(psn_ctx *const *ctxs, int32_t count, const psn_layout *layouts, int64_t stride,
+                          int32_t dst_device, void *dst);
+
+/* Number of device / pinned-host allocations the library has made in this process so far.  A
+ * caller can bracket a warm scheduling round with it: the per-round calls (psn_patch_arcs,
+ * psn_update_*, psn_reprice_costs, psn_settle_sources, psn_solve, psn_get_placements, and
+ * psn_solve_batch over an unchanged set of contexts) reuse what earlier rounds allocated. */
+uint64_t psn_debug_alloc_count(void);
 
 /* Per-kernel-class device time (ms) and launch counts of the last psn_solve, measured
  * with HIP events on the solver's stream; all zero unless the context was created with

@@ -74,6 +74,14 @@ typedef struct psn_svc_config {
     int32_t slots_per_machine; /* machine -> sink capacity; 0 -> 12 */
     int32_t unsched_cost;      /* cost of leaving a task unscheduled; 0 -> 2 560 000 */
     int32_t emit_noop;         /* 1: report unchanged tasks as NOOP deltas too */
+    int32_t reschedule_running;/* 0 (default): a task that has been placed keeps its machine until it
+                                  completes, fails, is removed or the machine goes away; it leaves the
+                                  network, its request counts as usage of the machine and it holds one of
+                                  the machine's slots, so a round only ever answers PLACE (the unmodified
+                                  client turns MIGRATE and PREEMPT into pod deletions,
+                                  /root/reference/cmd/poseidon/poseidon.go:52-63).  1: every runnable task
+                                  is re-optimised in every round and may be migrated or preempted (what-if
+                                  and defragmentation runs; the incremental benchmark configuration). */
     psn_config solver;         /* passed to psn_create (device field overwritten) */
 } psn_svc_config;
 
@@ -96,6 +104,9 @@ typedef struct psn_svc_stats {
     double build_ms, upload_ms, update_ms, solve_ms, extract_ms; /* last Schedule, host clock */
     int64_t total_cost;
     int32_t last_round_warm;
+    int64_t tasks_running;   /* tasks that hold a machine outside the network (reschedule_running = 0) */
+    int64_t tasks_deferred;  /* last Schedule: placements not admitted because the request no longer fitted next
+                                to what other classes were given on that machine in the same round */
 } psn_svc_stats;
 
 int psn_svc_create(const psn_svc_config *cfg, psn_svc **out);
@@ -134,7 +145,8 @@ int psn_svc_node_removed(psn_svc *svc, const char *resource_uuid);
 int psn_svc_node_labels(psn_svc *svc, const char *resource_uuid, const char *const *keys,
                         const char *const *values, int32_t n_labels);
 /* AddNodeStats (:42): resources in use on the machine by anything that is not one of the
- * tasks known to the service; feeds the cost model.  Reply as for NodeUpdated. */
+ * tasks known to the service; feeds the cost model, where the requests of the tasks the service
+ * has running on the machine are added to it.  Reply as for NodeUpdated. */
 int psn_svc_add_node_stats(psn_svc *svc, const char *resource_uuid, int64_t used_cpu_millicores, int64_t used_ram_kb);
 /* AddTaskStats (:40): accepted and ignored (the client ignores the reply,
  * /root/reference/pkg/firmament/firmament_client.go:183-188). */

@@ -88,17 +88,62 @@ def ssp(g):
     return rc, tc.value, cap, pot
 
 
-def cost_scaling(g, alpha: int = 12):
+CS_EPS_PERCENTILE, CS_PRICE_REFINE = 1, 2
+# The timed CPU baseline: the plain textbook variant (the one the parity tests use as the oracle)
+# and the tuned one (the GPU solver's first epsilon and alpha = 16, price refinement before each
+# later phase).  Arc fixing and push look-ahead are not implemented.
+BASELINE_VARIANTS = {
+    "plain (eps from max cost, alpha 12)": {},
+    "tuned (eps from 90th-percentile cost, alpha 16, price refinement)": {"alpha": 16, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE},
+}
+
+
+def use_native_build() -> str:
+    """For the timed CPU baseline: compile the oracle for the host this process runs on
+    (-O3 -march=native) into a temporary directory and use that copy from now on.  Falls back to
+    the shipped build when no compiler is at hand.  Returns the flags in use."""
+    global _lib, _native_flags
+    import shutil
+    import tempfile
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc:
+        out = os.path.join(tempfile.mkdtemp(prefix="psn_oracle_"), "libpsn_oracle_native.so")
+        flags = ["-O3", "-march=native", "-fPIC", "-shared"]
+        try:
+            subprocess.check_call([cc] + flags + ["-o", out, os.path.join(_HERE, "psn_oracle.c")])
+            lib()  # make sure the default is loadable first (keeps error messages sane)
+            _lib = None
+            globals()["_SO"] = out
+            lib()
+            _native_flags = os.path.basename(cc) + " " + " ".join(flags) + " (built on this host)"
+        except (subprocess.CalledProcessError, OSError):
+            pass
+    return build_flags()
+
+
+_native_flags = None
+
+
+def build_flags() -> str:
+    if _native_flags:
+        return _native_flags
+    try:
+        return open(os.path.join(_HERE, "build", "flags.txt")).read().strip()
+    except OSError:
+        return "unknown"
+
+
+def cost_scaling(g, alpha: int = 12, flags: int = 0):
     """-> (rc, total_cost, residual_cap, scaled_prices, Stats)"""
     cap = g.cap.copy()
     tc = C.c_int64(0)
     price = np.zeros(g.n, np.int64)
     st = Stats()
-    rc = lib().psn_oracle_cost_scaling(C.c_int32(g.n), C.c_int64(_m2(g)), _p(g.row_off, np.int64),
-                                       _p(g.head, np.int32), _p(cap, np.int32),
-                                       _p(g.cost, np.int32), _p(g.rev, np.int32),
-                                       _p(g.supply, np.int64), C.c_int32(alpha), C.byref(tc),
-                                       _p(price, np.int64), C.byref(st))
+    rc = lib().psn_oracle_cost_scaling_ex(C.c_int32(g.n), C.c_int64(_m2(g)), _p(g.row_off, np.int64),
+                                          _p(g.head, np.int32), _p(cap, np.int32),
+                                          _p(g.cost, np.int32), _p(g.rev, np.int32),
+                                          _p(g.supply, np.int64), C.c_int32(alpha), C.c_int32(flags), C.byref(tc),
+                                          _p(price, np.int64), C.byref(st))
     return rc, tc.value, cap, price, st
 
 

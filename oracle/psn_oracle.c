@@ -416,11 +416,57 @@ static int cs_refine(cs_ctx *c, i64 eps) {
     return ORC_OK;
 }
 
+/* Price refinement (Goldberg 1997, section 5, in label-correcting form): before refine(eps)
+ * moves any flow, look for prices under which the CURRENT flow is already eps-optimal, i.e.
+ * d with d(u) <= d(v) + rc(u,v) + eps on every residual arc (u,v); then price += d does it and
+ * the phase is skipped.  FIFO label correcting from d = 0; gives up (returns 0, prices
+ * untouched) when the scan budget is used up, which is what a negative cycle looks like. */
+static int cs_price_refine(cs_ctx *c, i64 eps) {
+    const i32 n = c->n;
+    for (i32 v = 0; v < n; ++v) if (c->excess[v] != 0) return 0; /* needs a flow, not a pseudoflow */
+    i64 *d = c->dist;
+    memset(c->inq, 0, n);
+    c->qh = c->qt = 0;
+    for (i32 v = 0; v < n; ++v) { d[v] = 0; cs_enqueue(c, v); }
+    i64 budget = 3 * c->m2 + 16 * (i64)n;
+    while (c->qh != c->qt) {
+        i32 v = c->q[c->qh];
+        if (++c->qh == c->qcap) c->qh = 0;
+        c->inq[v] = 0;
+        /* arcs (u,v) entering v: the reverse entries of v's row */
+        for (i64 a = c->row_off[v]; a < c->row_off[v + 1]; ++a) {
+            i64 r = c->rev[a];
+            c->st.arc_scans++;
+            if (c->cap[r] <= 0) continue;
+            i32 u = c->head[a];
+            i64 l = (i64)c->cost[r] * c->S + c->price[u] - c->price[v] + eps;
+            if (d[v] + l < d[u]) { d[u] = d[v] + l; cs_enqueue(c, u); }
+        }
+        budget -= c->row_off[v + 1] - c->row_off[v];
+        if (budget < 0) { memset(c->inq, 0, n); c->qh = c->qt = 0; return 0; }
+    }
+    for (i32 v = 0; v < n; ++v) c->price[v] += d[v];
+    return 1;
+}
+
+#define ORC_CS_EPS_PERCENTILE 1 /* first epsilon from the 90th-percentile cost (valid when no usable arc has a negative cost) */
+#define ORC_CS_PRICE_REFINE 2   /* try price refinement before every phase but the first */
+
 /* cap[] in: original residual capacities; out: final residual capacities.
- * price_out (may be NULL): scaled prices, 1-optimal w.r.t. cost*(n+1). */
+ * price_out (may be NULL): scaled prices, 1-optimal w.r.t. cost*(n+1).
+ * flags = 0 is the plain textbook variant the parity tests use as the oracle; the flags add the
+ * heuristics a tuned sequential solver has, for the timed CPU baseline. */
+int psn_oracle_cost_scaling_ex(i32 n, i64 m2, const i64 *row_off, const i32 *head, i32 *cap,
+                               const i32 *cost, const i32 *rev, const i64 *supply, i32 alpha, i32 flags,
+                               i64 *total_cost, i64 *price_out, psn_oracle_stats *stats);
 int psn_oracle_cost_scaling(i32 n, i64 m2, const i64 *row_off, const i32 *head, i32 *cap,
                             const i32 *cost, const i32 *rev, const i64 *supply, i32 alpha,
                             i64 *total_cost, i64 *price_out, psn_oracle_stats *stats) {
+    return psn_oracle_cost_scaling_ex(n, m2, row_off, head, cap, cost, rev, supply, alpha, 0, total_cost, price_out, stats);
+}
+int psn_oracle_cost_scaling_ex(i32 n, i64 m2, const i64 *row_off, const i32 *head, i32 *cap,
+                               const i32 *cost, const i32 *rev, const i64 *supply, i32 alpha, i32 flags,
+                               i64 *total_cost, i64 *price_out, psn_oracle_stats *stats) {
     cs_ctx c;
     memset(&c, 0, sizeof(c));
     int rc = ORC_OK;
@@ -456,12 +502,36 @@ int psn_oracle_cost_scaling(i32 n, i64 m2, const i64 *row_off, const i32 *head, 
         if (cap[a] > 0 && cc * c.S > eps) eps = cc * c.S;
     }
     if (eps < 1) eps = 1;
-    do {
-        eps = eps / alpha;
-        if (eps < 1) eps = 1;
-        rc = cs_refine(&c, eps);
-        if (rc) goto out;
-    } while (eps > 1);
+    if (flags & ORC_CS_EPS_PERCENTILE) {
+        /* zero flow with zero prices is 0-optimal when no usable arc has a negative cost, so the
+         * first phase may start anywhere; the 90th-percentile cost skips the phases in which only
+         * the few most expensive arcs are distinguishable */
+        i64 hist[33], total = 0, run = 0, neg = 0;
+        memset(hist, 0, sizeof(hist));
+        for (i64 a = 0; a < m2; ++a) {
+            if (cap[a] <= 0) continue;
+            if (cost[a] < 0) { ++neg; continue; }
+            int b = 0;
+            while (b < 32 && ((i64)1 << b) < cost[a]) ++b;
+            hist[b]++; total++;
+        }
+        if (!neg)
+            for (int b = 0; b < 32; ++b) {
+                run += hist[b];
+                if (run * 10 >= total * 9) { i64 e2 = ((i64)1 << b) * c.S; if (e2 < eps) eps = e2; break; }
+            }
+    }
+    {
+        int first = 1;
+        do {
+            eps = eps / alpha;
+            if (eps < 1) eps = 1;
+            if (!first && (flags & ORC_CS_PRICE_REFINE) && cs_price_refine(&c, eps)) { first = 0; continue; }
+            first = 0;
+            rc = cs_refine(&c, eps);
+            if (rc) goto out;
+        } while (eps > 1);
+    }
     c.st.solve_ms = now_ms() - t0;
     {
         i64 tc = 0;

@@ -34,6 +34,7 @@ EXPORTS = [
     "psn_svc_node_added", "psn_svc_node_updated", "psn_svc_node_failed", "psn_svc_node_removed",
     "psn_svc_add_node_stats", "psn_svc_check", "psn_svc_schedule", "psn_svc_get_deltas", "psn_svc_get_stats",
     "psn_svc_task_submitted_sel", "psn_svc_node_labels", "psn_svc_export_mask", "psn_svc_network_size", "psn_svc_export_network", "psn_svc_task_placement", "psn_svc_solver",
+    "psn_gather_placements", "psn_debug_alloc_count",
 ]
 
 
@@ -54,7 +55,7 @@ class Result(C.Structure):
                 ("vertex_visits", C.c_uint64), ("gu_arc_scans", C.c_uint64),
                 ("gu_relaxations", C.c_uint64), ("sat_arc_scans", C.c_uint64), ("rounds", C.c_uint64),
                 ("gu_iterations", C.c_uint64), ("global_updates", C.c_uint64), ("launches", C.c_uint64),
-                ("solve_ms", C.c_double)]
+                ("solve_ms", C.c_double), ("gu_arc_skips", C.c_uint64)]
 
 
 class Layout(C.Structure):
@@ -107,6 +108,9 @@ def load_library():
     lib.psn_dimacs_write.argtypes = [C.c_char_p, i32, i64, vp, vp, vp, vp, vp, C.c_char_p]
     lib.psn_dimacs_size.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i64)]
     lib.psn_dimacs_read.argtypes = [C.c_char_p, i32, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    lib.psn_gather_placements.argtypes = [vp, i32, vp, i64, i32, vp]
+    lib.psn_debug_alloc_count.restype = u64
+    lib.psn_debug_alloc_count.argtypes = []
     lib.psn_fnv1a64.restype = u64
     lib.psn_fnv1a64.argtypes = [vp, i64, u64]
     _lib = lib

@@ -43,7 +43,8 @@ struct psn_ctx {
     int tally_slots = 0;
     // class x machine admission mask (label selectors), applied by the cost kernel when set
     unsigned *d_allow = nullptr;
-    int allow_words = 0, allow_classes = 0;
+    int allow_words = 0, allow_classes = 0;  // shape the buffer was allocated for
+    bool allow_on = false;
     // placements scratch
     int *d_place = nullptr, *d_slot_machine = nullptr;
     long long place_count = 0, slot_stride = 0, slot_classes = 0;
@@ -59,6 +60,17 @@ struct psn_ctx {
     size_t kt_used = 0;
     double kt_ms[PSN_KT_CLASSES] = {0};
     uint64_t kt_calls[PSN_KT_CLASSES] = {0};
+    // host copy of the row offsets of the uploaded network: layouts handed to the cost model and
+    // to placement extraction are checked against it before any kernel indexes with them
+    std::vector<unsigned> h_row;
+    // grow-only device staging for the per-round update calls (kept across uploads), and a
+    // pinned word block for small read-backs
+    char *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    unsigned *h_flag = nullptr;  // pinned, kFlagWords words
+    // identity for caches that outlive a call: never reused, bumped on every upload
+    unsigned long long serial = 0, upload_gen = 0;
+    struct GroupCache *gcache = nullptr;  // lockstep group led by this context, kept between batch calls
 };
 
 namespace {
@@ -76,23 +88,60 @@ int fail(psn_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
         if (e_ != hipSuccess) return fail((c), PSN_EDEVICE, #call, e_);   \
     } while (0)
 
+// Every device or pinned allocation the library makes goes through counted_malloc /
+// counted_host_malloc, so that a caller (or a test) can see that a warm scheduling round
+// allocates nothing: psn_debug_alloc_count().
+std::atomic<unsigned long long> g_alloc_calls{0};
+std::atomic<unsigned long long> g_ctx_serial{0};
+hipError_t counted_malloc(void **p, size_t bytes) {
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+    return hipMalloc(p, bytes);
+}
+hipError_t counted_host_malloc(void **p, size_t bytes) {
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+    return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+constexpr int kFlagWords = 16;
+
 template <typename T>
 int dalloc(psn_ctx *c, T **p, size_t count) {
     void *q = nullptr;
-    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    hipError_t e = counted_malloc(&q, std::max<size_t>(count, 1) * sizeof(T));
     if (e != hipSuccess) return fail(c, PSN_ENOMEM, "hipMalloc", e);
     c->bufs.push_back(q);
     *p = static_cast<T *>(q);
     return PSN_OK;
 }
+// Device staging of at least `bytes` for one update call: grows by half when it has to, else reused.
+int stage(psn_ctx *c, size_t bytes, char **out) {
+    if (bytes > c->stage_bytes) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(c, PSN_EDEVICE, "hipStreamSynchronize", e);
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        c->d_stage = nullptr;
+        c->stage_bytes = 0;
+        const size_t want = std::max<size_t>((size_t)1 << 20, bytes + bytes / 2);
+        void *q = nullptr;
+        e = counted_malloc(&q, want);
+        if (e != hipSuccess) return fail(c, PSN_ENOMEM, "hipMalloc (staging)", e);
+        c->d_stage = static_cast<char *>(q);
+        c->stage_bytes = want;
+    }
+    *out = c->d_stage;
+    return PSN_OK;
+}
+void drop_group_cache(psn_ctx *c);
 void free_graph_buffers(psn_ctx *c) {
+    drop_group_cache(c);
     if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
     if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
     for (void *p : c->bufs) (void)hipFree(p);
     c->bufs.clear();
+    c->h_row.clear();
+    ++c->upload_gen;
     c->uploaded = c->solved = false;
     c->d_place = c->d_slot_machine = nullptr;
-    c->d_allow = nullptr; c->allow_words = c->allow_classes = 0;
+    c->d_allow = nullptr; c->allow_words = c->allow_classes = 0; c->allow_on = false;
     c->place_count = c->slot_stride = c->slot_classes = 0;
 }
 
@@ -226,7 +275,16 @@ __global__ void k_max_violation(DevGraph g, i64 *out) {
     if ((threadIdx.x & 63) == 0 && mx > 0) __hip_atomic_fetch_max(out, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sum of the supplies of the resident network (psn_update_supplies may have unbalanced them).
+__global__ void k_sum_supply(const i64 *supply, int n, i64 *out) {
+    i64 sm = 0;
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) sm += supply[v];
+    sm = (i64)wave_sum_u64((unsigned long long)sm);
+    if ((threadIdx.x & 63) == 0 && sm) __hip_atomic_fetch_add(out, sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr int kScalarSlots = 40;
+constexpr int kSupplySumSlot = 38;  // d_scalar: [0] total cost, [1] max violation, [2..35] cost statistics, [38] supply sum
 #ifdef PSN_STAMPS
 constexpr size_t kStampWords = (size_t)65536 + (size_t)8 * 64 * 4096 * 2 + (size_t)8 * 64 * 2;
 #endif
@@ -277,8 +335,10 @@ int psn_create(const psn_config *cfg, psn_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_ctrl, sizeof(Ctrl), hipHostMallocDefault);
+    if (e == hipSuccess) e = counted_host_malloc((void **)&c->h_ctrl, sizeof(Ctrl));
+    if (e == hipSuccess) e = counted_host_malloc((void **)&c->h_flag, kFlagWords * sizeof(unsigned));
     if (e != hipSuccess) { psn_destroy(c); return PSN_EDEVICE; }
+    c->serial = g_ctx_serial.fetch_add(1) + 1;
     *out = c;
     return PSN_OK;
 }
@@ -289,6 +349,8 @@ void psn_destroy(psn_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->kt_ev) (void)hipEventDestroy(e);
     free_graph_buffers(c);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->h_ctrl) (void)hipHostFree(c->h_ctrl);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -320,7 +382,8 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     c->n = n;
     c->m2 = m2;
     // ---- classify vertices by degree
-    std::vector<unsigned> row((size_t)n + 1);
+    std::vector<unsigned> &row = c->h_row;
+    row.assign((size_t)n + 1, 0u);
     std::vector<unsigned char> cls((size_t)n);
     long long high_items = 0;
     for (int32_t v = 0; v <= n; ++v) row[(size_t)v] = (unsigned)row_off[v];
@@ -454,10 +517,27 @@ static int eval_costs_impl(psn_ctx *c, const psn_layout *lay, const int64_t *cap
             return fail(c, PSN_EOVERFLOW, "machine quantity too large");
     }
     if ((long long)1 + N + E > c->n) return fail(c, PSN_EINVAL, "layout does not match the uploaded network");
+    // rows of the uploaded network must hold what the layout says: E * K reverse slot arcs at the start of
+    // every machine row, N * K slot arcs from ec_arc_base[e] on inside the row of class e
+    for (int m = 0; m < N; ++m)
+        if ((long long)c->h_row[(size_t)m + 2] - c->h_row[(size_t)m + 1] < (long long)E * K)
+            return fail(c, PSN_EINVAL, "a machine row is shorter than classes x slots: layout does not match the uploaded network");
+    for (int e = 0; e < E; ++e) {
+        const long long lo = c->h_row[(size_t)1 + N + e], hi = c->h_row[(size_t)2 + N + e];
+        if (ec_arc_base[e] < lo || ec_arc_base[e] + (int64_t)N * K > hi)
+            return fail(c, PSN_EINVAL, "ec_arc_base does not lie inside the row of its class");
+    }
+    // an admission mask belongs to one (classes, machines) shape; pricing another shape under it would
+    // silently lift the selectors
+    if (c->allow_on && (c->allow_classes != E || c->allow_words != (N + 31) / 32))
+        return fail(c, PSN_EINVAL, "admission mask was set for another layout");
     HIPCHK(c, hipSetDevice(c->device));
-    i64 *d;  // one staging allocation: 4 machine arrays, 2 shape arrays, bases, layout-check counter
+    // staging: 4 machine arrays, 2 shape arrays, bases, layout-check counter
     const size_t cnt = 4 * (size_t)N + 3 * (size_t)E + 1;
-    HIPCHK(c, hipMalloc((void **)&d, cnt * sizeof(i64)));
+    char *dst;
+    int rcs = stage(c, cnt * sizeof(i64), &dst);
+    if (rcs != PSN_OK) return rcs;
+    i64 *d = reinterpret_cast<i64 *>(dst);
     std::vector<i64> h(cnt);
     std::copy(cap_cpu, cap_cpu + N, h.begin());
     std::copy(cap_mem, cap_mem + N, h.begin() + N);
@@ -468,25 +548,23 @@ static int eval_costs_impl(psn_ctx *c, const psn_layout *lay, const int64_t *cap
     std::copy(ec_arc_base, ec_arc_base + E, h.begin() + 4 * (size_t)N + 2 * (size_t)E);
     h[cnt - 1] = 0;
     unsigned *d_bad = reinterpret_cast<unsigned *>(d + cnt - 1);
-    unsigned bad = 0;
     hipError_t e = hipMemcpyAsync(d, h.data(), cnt * sizeof(i64), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         const long long total = 2LL * E * N;
         const int grid = (int)std::min<long long>((total + kBlock - 1) / kBlock, 8192);
+        const i64 *d_base = d + 4 * (size_t)N + 2 * (size_t)E;
+        // the layout pass writes nothing but its counter; the cost kernel returns at once when it is nonzero
+        hipLaunchKernelGGL(k_check_slot_layout, dim3(std::max(1, grid / 2)), dim3(kBlock), 0, c->stream, c->g, E, N, K, d_base, d_bad);
         hipLaunchKernelGGL(k_eval_costs, dim3(grid), dim3(kBlock), 0, c->stream, c->g, E, N, K, d, d + N, d + 2 * (size_t)N,
-                           d + 3 * (size_t)N, d + 4 * (size_t)N, d + 4 * (size_t)N + E, d + 4 * (size_t)N + 2 * (size_t)E, c->d_cost,
-                           c->d_ocap, keep_flow, (c->d_allow && c->allow_classes == E && c->allow_words == (N + 31) / 32) ? c->d_allow : nullptr,
-                           c->allow_words, d_bad);
+                           d + 3 * (size_t)N, d + 4 * (size_t)N, d + 4 * (size_t)N + E, d_base, c->d_cost,
+                           c->d_ocap, keep_flow, c->allow_on ? c->d_allow : nullptr, c->allow_words, d_bad);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_flag, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // also: the host staging vector dies at return
     if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_eval_costs", e);
-    if (bad) {
-        c->solved = false;
-        return fail(c, PSN_EINVAL, "machine rows do not start with the reverse slot arcs, class-major and slot-minor");
-    }
+    if (c->h_flag[0])  // nothing was written: the resident network and its solved state stand as they were
+        return fail(c, PSN_EINVAL, "slot arcs and their reverse arcs do not pair up class-major, slot-minor at the start of the machine rows");
     if (!keep_flow) c->solved = false;  // the flow on re-priced arcs was reset
     return PSN_OK;
 }
@@ -506,7 +584,8 @@ int psn_set_admission_mask(psn_ctx *c, const psn_layout *lay, const uint32_t *ma
     if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
     const int N = lay->n_machines, E = lay->n_classes;
     if (N <= 0 || E <= 0) return fail(c, PSN_EINVAL, "bad layout");
-    if (!mask) { c->allow_classes = 0; return PSN_OK; }  // every class may use every machine again
+    if (!mask) { c->allow_on = false; return PSN_OK; }  // every class may use every machine again
+    if ((long long)1 + N + E > c->n) return fail(c, PSN_EINVAL, "layout does not match the uploaded network");
     const int words = (N + 31) / 32;
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->d_allow || c->allow_words != words || c->allow_classes != E) {
@@ -517,6 +596,7 @@ int psn_set_admission_mask(psn_ctx *c, const psn_layout *lay, const uint32_t *ma
     }
     HIPCHK(c, hipMemcpyAsync(c->d_allow, mask, (size_t)E * words * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->allow_on = true;
     return PSN_OK;
 }
 
@@ -536,7 +616,7 @@ int psn_patch_arcs(psn_ctx *c, int64_t count, const int64_t *arc_index, const in
     // one staging block: indices (8 B) then four int arrays
     const size_t bytes = (size_t)count * (sizeof(i64) + 4 * sizeof(int)) + sizeof(unsigned);
     char *d;
-    HIPCHK(c, hipMalloc((void **)&d, bytes));
+    { const int rcs = stage(c, bytes, &d); if (rcs != PSN_OK) return rcs; }
     i64 *d_idx = (i64 *)d;
     int *d_h = (int *)(d + (size_t)count * sizeof(i64)), *d_c = d_h + count, *d_k = d_c + count, *d_r = d_k + count;
     unsigned *d_bad = (unsigned *)(d_r + count);
@@ -555,10 +635,10 @@ int psn_patch_arcs(psn_ctx *c, int64_t count, const int64_t *arc_index, const in
         hipLaunchKernelGGL(k_check_patched, dim3(grid), dim3(kBlock), 0, s, c->g, (long long)count, d_idx, d_bad);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_flag, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_patch_arcs", e);
+    bad = c->h_flag[0];
     if (bad) {
         c->uploaded = c->solved = false;  // the device network is inconsistent: upload again
         return fail(c, PSN_EINVAL, "patched arcs do not pair up; the network must be uploaded again");
@@ -575,7 +655,7 @@ int psn_settle_sources(psn_ctx *c, int64_t count, const int32_t *vertex, int64_t
         if (vertex[i] < 0 || vertex[i] >= c->n) return fail(c, PSN_EINVAL, "vertex out of range");
     HIPCHK(c, hipSetDevice(c->device));
     char *d;
-    HIPCHK(c, hipMalloc((void **)&d, (size_t)count * sizeof(int) + sizeof(unsigned)));
+    { const int rcs = stage(c, (size_t)count * sizeof(int) + sizeof(unsigned), &d); if (rcs != PSN_OK) return rcs; }
     int *d_v = (int *)d;
     unsigned *d_skip = (unsigned *)(d_v + count);
     unsigned skip = 0;
@@ -587,10 +667,10 @@ int psn_settle_sources(psn_ctx *c, int64_t count, const int32_t *vertex, int64_t
         hipLaunchKernelGGL(k_settle_sources, dim3(grid), dim3(kBlock), 0, s, c->g, (long long)count, d_v, d_skip);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&skip, d_skip, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_flag, d_skip, sizeof(unsigned), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_settle_sources", e);
+    skip = c->h_flag[0];
     if (skipped) *skipped = (int64_t)skip;
     return PSN_OK;
 }
@@ -602,11 +682,11 @@ int psn_update_caps(psn_ctx *c, int64_t count, const int64_t *arc_index, const i
     for (int64_t i = 0; i < count; ++i)
         if (arc_index[i] < 0 || arc_index[i] >= c->m2 || new_cap[i] < 0) return fail(c, PSN_EINVAL, "arc index or capacity out of range");
     HIPCHK(c, hipSetDevice(c->device));
-    i64 *d_idx; int *d_cap;
-    HIPCHK(c, hipMalloc((void **)&d_idx, (size_t)count * sizeof(i64)));
-    hipError_t e = hipMalloc((void **)&d_cap, (size_t)count * sizeof(int));
-    if (e != hipSuccess) { (void)hipFree(d_idx); return fail(c, PSN_ENOMEM, "hipMalloc", e); }
-    e = hipMemcpyAsync(d_idx, arc_index, (size_t)count * sizeof(i64), hipMemcpyHostToDevice, c->stream);
+    char *d;
+    { const int rcs = stage(c, (size_t)count * (sizeof(i64) + sizeof(int)), &d); if (rcs != PSN_OK) return rcs; }
+    i64 *d_idx = (i64 *)d;
+    int *d_cap = (int *)(d_idx + count);
+    hipError_t e = hipMemcpyAsync(d_idx, arc_index, (size_t)count * sizeof(i64), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_cap, new_cap, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         const int grid = (int)std::min<long long>((count + kBlock - 1) / kBlock, 1024);
@@ -615,7 +695,6 @@ int psn_update_caps(psn_ctx *c, int64_t count, const int64_t *arc_index, const i
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_idx); (void)hipFree(d_cap);
     if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_update_caps", e);
     return PSN_OK;
 }
@@ -627,11 +706,11 @@ int psn_update_supplies(psn_ctx *c, int64_t count, const int32_t *vertex, const 
     for (int64_t i = 0; i < count; ++i)
         if (vertex[i] < 0 || vertex[i] >= c->n) return fail(c, PSN_EINVAL, "vertex out of range");
     HIPCHK(c, hipSetDevice(c->device));
-    int *d_v; i64 *d_s;
-    HIPCHK(c, hipMalloc((void **)&d_v, (size_t)count * sizeof(int)));
-    hipError_t e = hipMalloc((void **)&d_s, (size_t)count * sizeof(i64));
-    if (e != hipSuccess) { (void)hipFree(d_v); return fail(c, PSN_ENOMEM, "hipMalloc", e); }
-    e = hipMemcpyAsync(d_v, vertex, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    char *d;
+    { const int rcs = stage(c, (size_t)count * (sizeof(i64) + sizeof(int)), &d); if (rcs != PSN_OK) return rcs; }
+    i64 *d_s = (i64 *)d;
+    int *d_v = (int *)(d_s + count);
+    hipError_t e = hipMemcpyAsync(d_v, vertex, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_s, new_supply, (size_t)count * sizeof(i64), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         const int grid = (int)std::min<long long>((count + kBlock - 1) / kBlock, 1024);
@@ -639,7 +718,6 @@ int psn_update_supplies(psn_ctx *c, int64_t count, const int32_t *vertex, const 
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_v); (void)hipFree(d_s);
     if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_update_supplies", e);
     return PSN_OK;
 }
@@ -657,6 +735,7 @@ static int solve_prepare(psn_ctx *c, hipStream_t s, bool warm, i64 *h_scalar) {
     if (g.dbg_cnt) HIPCHK(c, hipMemsetAsync(g.dbg_cnt, 0, sizeof(unsigned), s));
     if (!warm) hipLaunchKernelGGL(k_cost_stats, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 2);
     if (warm) hipLaunchKernelGGL(k_max_violation, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 1);
+    hipLaunchKernelGGL(k_sum_supply, dim3(std::max(1, std::min(64, (g.n + kBlock - 1) / kBlock))), dim3(kBlock), 0, s, c->d_supply, g.n, c->d_scalar + kSupplySumSlot);
     HIPCHK(c, hipMemcpyAsync(h_scalar, c->d_scalar, kScalarSlots * sizeof(i64), hipMemcpyDeviceToHost, s));
     return PSN_OK;
 }
@@ -690,6 +769,8 @@ static int solve_start(psn_ctx *c, hipStream_t s, bool warm, const i64 *h_scalar
     init.eps_shift = shift0;
     init.eps = (i64)1 << shift0;
     init.need_sat = 1;
+    // supplies that do not sum to zero cannot be routed: the solve ends at its first control step
+    if (h_scalar[kSupplySumSlot] != 0) init.error = PSN_EINFEASIBLE_DEV;
     *c->h_ctrl = init;
     HIPCHK(c, hipMemcpyAsync(g.ctrl, c->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice, s));
     return PSN_OK;
@@ -722,6 +803,7 @@ static void solve_report(psn_ctx *c, psn_result *out, int status, i64 cost, cons
     out->global_updates = c->h_ctrl->tally_gus;
     out->launches = (uint64_t)replays * (uint64_t)launches_per_replay;
     out->solve_ms = ms;
+    out->gu_arc_skips = h_tally[kTallyGuSkips];
     c->solved = status == PSN_OK;
 }
 
@@ -734,7 +816,6 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     for (int i = 0; i < PSN_KT_CLASSES; ++i) { c->kt_ms[i] = 0; c->kt_calls[i] = 0; }
     hipStream_t s = c->stream;
     const DevGraph &g = c->g;
-    // supplies must still balance (psn_update_supplies may have changed them)
     HIPCHK(c, hipEventRecord(c->ev0, s));
     i64 h_scalar[kScalarSlots] = {};
     int rc = solve_prepare(c, s, warm, h_scalar);
@@ -795,7 +876,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
                 (unsigned long long)out->rounds, (unsigned long long)out->global_updates, (unsigned long long)out->gu_iterations, (unsigned long long)out->pushes,
                 (unsigned long long)out->relabels, ms);
     if (dbg_phases) fprintf(stderr, "   replays per phase (shift:replays)%s %d:%lld\n", phase_log.c_str(), last_shift, phase_replays);
-    if (status != PSN_OK) return fail(c, status, "solve did not converge");
+    if (status != PSN_OK) return fail(c, status, h_scalar[kSupplySumSlot] != 0 ? "supplies do not sum to zero" : "solve did not converge");
     return PSN_OK;
 }
 
@@ -838,61 +919,95 @@ int group_enqueue_replay(const std::vector<psn_ctx *> &m, const DevGraph *d_grap
     return PSN_OK;
 }
 
+}  // namespace
+
+// What a lockstep group needs between replays, kept by the group's first member from one batch
+// call to the next: the table of member networks in device memory, the status words and the
+// instantiated replay graph.  Valid while the same contexts, in the same order, hold the same
+// uploads; anything else builds it anew.
+struct GroupCache {
+    std::vector<std::pair<unsigned long long, unsigned long long>> key;  // (serial, upload generation) per member
+    DevGraph *d_graphs = nullptr;
+    int *d_status = nullptr, *h_status = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    int launches = 0;
+};
+
+namespace {
+void drop_group_cache(psn_ctx *c) {
+    GroupCache *gc = c->gcache;
+    if (!gc) return;
+    if (gc->gexec) (void)hipGraphExecDestroy(gc->gexec);
+    if (gc->graph) (void)hipGraphDestroy(gc->graph);
+    if (gc->d_graphs) (void)hipFree(gc->d_graphs);
+    if (gc->d_status) (void)hipFree(gc->d_status);
+    if (gc->h_status) (void)hipHostFree(gc->h_status);
+    delete gc;
+    c->gcache = nullptr;
+}
+
 // Solves the members together; out[i] belongs to m[i].  Returns the first member's error, if any.
 int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *const *out) {
     psn_ctx *lead = m[0];
     const size_t G = m.size();
     hipStream_t s = lead->stream;
     HIPCHK(lead, hipSetDevice(lead->device));
-    DevGraph *d_graphs = nullptr;
-    int *d_status = nullptr, *h_status = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
     std::vector<i64> h_scalar(G * kScalarSlots, 0), h_cost(G, 0);
     std::vector<unsigned long long> h_tally(G * kTallyN, 0);
     std::vector<char> warm(G, 0);
     std::vector<int> status(G, PSN_OK);
-    int rc = PSN_OK, launches = 0;
+    int rc = PSN_OK;
     long long replays = 0;
     float ms = 0.f;
-    auto cleanup = [&]() {
-        if (gexec) (void)hipGraphExecDestroy(gexec);
-        if (graph) (void)hipGraphDestroy(graph);
-        if (d_graphs) (void)hipFree(d_graphs);
-        if (d_status) (void)hipFree(d_status);
-        if (h_status) (void)hipHostFree(h_status);
-    };
-#define GCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = fail(lead, PSN_EDEVICE, #call, e_); cleanup(); return rc; } } while (0)
+#define GCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { drop_group_cache(lead); return fail(lead, PSN_EDEVICE, #call, e_); } } while (0)
     const bool dbg_t = std::getenv("PSN_DEBUG_GROUP") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_a = now(), t_b = 0, t_c = 0, t_d = 0, t_e = 0;
-    GCHK(hipMalloc((void **)&d_graphs, G * sizeof(DevGraph)));
-    GCHK(hipMalloc((void **)&d_status, 2 * G * sizeof(int)));
-    GCHK(hipHostMalloc((void **)&h_status, 2 * G * sizeof(int), hipHostMallocDefault));
-    std::vector<DevGraph> h_graphs(G);
+    std::vector<std::pair<unsigned long long, unsigned long long>> key(G);
+    for (size_t i = 0; i < G; ++i) key[i] = std::make_pair(m[i]->serial, m[i]->upload_gen);
+    for (size_t i = 1; i < G; ++i) GCHK(hipStreamSynchronize(m[i]->stream));  // members' own earlier work (pricing) is done
+    bool fresh = false;
+    if (!lead->gcache || lead->gcache->key != key) {
+        drop_group_cache(lead);
+        GroupCache *gc = new (std::nothrow) GroupCache();
+        if (!gc) return fail(lead, PSN_ENOMEM, "group cache");
+        lead->gcache = gc;
+        gc->key = key;
+        GCHK(counted_malloc((void **)&gc->d_graphs, G * sizeof(DevGraph)));
+        GCHK(counted_malloc((void **)&gc->d_status, 2 * G * sizeof(int)));
+        GCHK(counted_host_malloc((void **)&gc->h_status, 2 * G * sizeof(int)));
+        std::vector<DevGraph> h_graphs(G);
+        for (size_t i = 0; i < G; ++i) h_graphs[i] = m[i]->g;
+        GCHK(hipMemcpyAsync(gc->d_graphs, h_graphs.data(), G * sizeof(DevGraph), hipMemcpyHostToDevice, s));
+        GCHK(hipStreamSynchronize(s));  // the host table dies with this block
+        fresh = true;
+    }
+    GroupCache *gc = lead->gcache;
     for (size_t i = 0; i < G; ++i) {
         std::memset(out[i], 0, sizeof(psn_result));
-        h_graphs[i] = m[i]->g;
         warm[i] = (flags & PSN_WARM_START) && m[i]->solved;
     }
     GCHK(hipEventRecord(lead->ev0, s));
-    GCHK(hipMemcpyAsync(d_graphs, h_graphs.data(), G * sizeof(DevGraph), hipMemcpyHostToDevice, s));
     for (size_t i = 0; i < G; ++i)
-        if ((rc = solve_prepare(m[i], s, warm[i], &h_scalar[i * kScalarSlots])) != PSN_OK) { cleanup(); return rc; }
+        if ((rc = solve_prepare(m[i], s, warm[i], &h_scalar[i * kScalarSlots])) != PSN_OK) return rc;
     GCHK(hipStreamSynchronize(s));
     for (size_t i = 0; i < G; ++i)
-        if ((rc = solve_start(m[i], s, warm[i], &h_scalar[i * kScalarSlots])) != PSN_OK) { cleanup(); return rc; }
+        if ((rc = solve_start(m[i], s, warm[i], &h_scalar[i * kScalarSlots])) != PSN_OK) return rc;
     t_b = now();
-    GCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    group_enqueue_replay(m, d_graphs, d_status, s, &launches);
-    GCHK(hipStreamEndCapture(s, &graph));  // ends the capture whether or not it yields a graph
-    GCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    if (fresh) {
+        GCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        group_enqueue_replay(m, gc->d_graphs, gc->d_status, s, &gc->launches);
+        GCHK(hipStreamEndCapture(s, &gc->graph));  // ends the capture whether or not it yields a graph
+        GCHK(hipGraphInstantiate(&gc->gexec, gc->graph, nullptr, nullptr, 0));
+    }
     t_c = now();
+    int *h_status = gc->h_status;
     const long long max_replays = 200000;
     for (;;) {
-        GCHK(hipGraphLaunch(gexec, s));
+        GCHK(hipGraphLaunch(gc->gexec, s));
         ++replays;
-        GCHK(hipMemcpyAsync(h_status, d_status, 2 * G * sizeof(int), hipMemcpyDeviceToHost, s));
+        GCHK(hipMemcpyAsync(h_status, gc->d_status, 2 * G * sizeof(int), hipMemcpyDeviceToHost, s));
         GCHK(hipStreamSynchronize(s));
         bool all = true;
         for (size_t i = 0; i < G; ++i) all = all && (h_status[2 * i] || h_status[2 * i + 1]);
@@ -905,19 +1020,21 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
     t_d = now();
     for (size_t i = 0; i < G; ++i) {
         if (h_status[2 * i + 1]) status[i] = h_status[2 * i + 1] == PSN_EINFEASIBLE_DEV ? PSN_EINFEASIBLE : PSN_EDEVICE;
-        if ((rc = solve_finish(m[i], s, &h_cost[i], &h_tally[i * kTallyN])) != PSN_OK) { cleanup(); return rc; }
+        if ((rc = solve_finish(m[i], s, &h_cost[i], &h_tally[i * kTallyN])) != PSN_OK) return rc;
     }
     GCHK(hipEventRecord(lead->ev1, s));
     GCHK(hipStreamSynchronize(s));
     GCHK(hipEventElapsedTime(&ms, lead->ev0, lead->ev1));
 #undef GCHK
     t_e = now();
-    cleanup();
-    if (dbg_t) fprintf(stderr, "group of %zu: alloc+prepare %.2f capture+instantiate %.2f replays(%lld) %.2f finish %.2f cleanup %.2f ms\n", G, t_b - t_a, t_c - t_b, replays, t_d - t_c, t_e - t_d, now() - t_e);
+    if (dbg_t) fprintf(stderr, "group of %zu (%s): prepare %.2f capture+instantiate %.2f replays(%lld) %.2f finish %.2f ms\n", G, fresh ? "new" : "cached", t_b - t_a, t_c - t_b, replays, t_d - t_c, t_e - t_d);
     rc = PSN_OK;
     for (size_t i = 0; i < G; ++i) {
-        solve_report(m[i], out[i], status[i], h_cost[i], &h_tally[i * kTallyN], replays, launches, ms);
-        if (status[i] != PSN_OK) { (void)fail(m[i], status[i], "solve did not converge"); if (rc == PSN_OK) rc = status[i]; }
+        solve_report(m[i], out[i], status[i], h_cost[i], &h_tally[i * kTallyN], replays, gc->launches, ms);
+        if (status[i] != PSN_OK) {
+            (void)fail(m[i], status[i], h_scalar[i * kScalarSlots + kSupplySumSlot] != 0 ? "supplies do not sum to zero" : "solve did not converge");
+            if (rc == PSN_OK) rc = status[i];
+        }
     }
     return rc;
 }
@@ -930,7 +1047,14 @@ int psn_solve_batch(psn_ctx *const *ctxs, int32_t count, uint32_t flags, int32_t
         for (int32_t j = i + 1; j < count; ++j)
             if (ctxs[i] == ctxs[j]) return PSN_EINVAL;  // a context runs one solve at a time
     for (int32_t i = 0; i < count; ++i) if (!ctxs[i]->uploaded) return fail(ctxs[i], PSN_ESTATE, "no graph uploaded");
-    if (workers <= 0) workers = 4;
+    // one host thread drives one group at a time; with contexts on several devices every device
+    // should have a thread of its own so that the devices work side by side
+    {
+        std::vector<int> devs;
+        for (int32_t i = 0; i < count; ++i) if (std::find(devs.begin(), devs.end(), ctxs[i]->device) == devs.end()) devs.push_back(ctxs[i]->device);
+        if (workers <= 0) workers = std::max<int32_t>(4, 2 * (int32_t)devs.size());
+        workers = std::max<int32_t>(workers, (int32_t)devs.size());
+    }
     // Contexts that can share a replay sequence (same device, same solver configuration, graph
     // replay on) are solved in lockstep groups; the groups are spread over the worker threads.
     int group_cap = 128;
@@ -952,9 +1076,31 @@ int psn_solve_batch(psn_ctx *const *ctxs, int32_t count, uint32_t flags, int32_t
             }
             const size_t parts = (same.size() + (size_t)group_cap - 1) / (size_t)group_cap;
             const size_t per = (same.size() + parts - 1) / parts;
-            for (size_t at = 0; at < same.size(); at += per)
-                groups.emplace_back(same.begin() + (long)at, same.begin() + (long)std::min(same.size(), at + per));
+            // A lockstep group pays for itself from about four members on: its launches carry every
+            // member's idle stages, and two or three networks finish sooner one after the other.
+            const size_t min_group = (size_t)std::min(4, group_cap);
+            for (size_t at = 0; at < same.size(); at += per) {
+                const size_t end = std::min(same.size(), at + per);
+                if (end - at >= min_group) groups.emplace_back(same.begin() + (long)at, same.begin() + (long)end);
+                else for (size_t x = at; x < end; ++x) groups.emplace_back(1, same[x]);
+            }
         }
+        // groups of different devices take turns in the work queue, so that the first `workers` groups
+        // picked up already cover every device
+        std::stable_sort(groups.begin(), groups.end(), [](const std::vector<int32_t> &a, const std::vector<int32_t> &b) { return a.size() > b.size(); });
+        std::vector<std::vector<int32_t>> by_turn;
+        std::vector<char> used(groups.size(), 0);
+        for (size_t left = groups.size(); left;) {
+            std::vector<int> seen;
+            for (size_t gi = 0; gi < groups.size(); ++gi) {
+                if (used[gi]) continue;
+                const int dev = ctxs[groups[gi][0]]->device;
+                if (std::find(seen.begin(), seen.end(), dev) != seen.end()) continue;
+                seen.push_back(dev); used[gi] = 1; --left;
+                by_turn.push_back(std::move(groups[gi]));
+            }
+        }
+        groups.swap(by_turn);
     }
     workers = std::min<int32_t>(workers, std::max<int32_t>((int32_t)groups.size(), 1));
     std::atomic<size_t> next{0};
@@ -1025,23 +1171,48 @@ int psn_get_costs(psn_ctx *c, int32_t *cost, int32_t *cap_orig) {
     return PSN_OK;
 }
 
-static int run_placements(psn_ctx *c, const psn_layout *lay) {
+constexpr int kPlaceBadSlot = 39;  // d_scalar word that counts arcs k_placements found out of place
+// Host-side check of a layout against the uploaded network, before any kernel indexes with it.
+static int check_place_layout(psn_ctx *c, const psn_layout *lay) {
     if (!lay) return fail(c, PSN_EINVAL, "null layout");
     if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
     const int N = lay->n_machines, E = lay->n_classes, J = lay->n_jobs, P = lay->n_tasks, K = lay->k_slots;
     if (N <= 0 || E <= 0 || J < 0 || P <= 0 || K <= 0 || (long long)1 + N + E + J + P != c->n)
         return fail(c, PSN_EINVAL, "layout does not match the uploaded network");
+    // every class row must end with its N * K slot arcs (the kernel splits the row there)
+    for (int e = 0; e < E; ++e)
+        if ((long long)c->h_row[(size_t)2 + N + e] - c->h_row[(size_t)1 + N + e] < (long long)N * K)
+            return fail(c, PSN_EINVAL, "a class row is shorter than machines x slots: layout does not match the uploaded network");
+    return PSN_OK;
+}
+// K5 on the context's stream: placements into dst (device, int32[P]); slot_machine (device,
+// int32[E * stride]) holds each class's units of flow in arc order while the kernel runs.  The
+// count of arcs found out of place is on its way to h_flag[1] when this returns.
+static int launch_placements(psn_ctx *c, const psn_layout *lay, int *dst, int *slot_machine, long long stride) {
+    const int N = lay->n_machines, E = lay->n_classes, J = lay->n_jobs, P = lay->n_tasks, K = lay->k_slots;
+    unsigned *d_bad = reinterpret_cast<unsigned *>(c->d_scalar + kPlaceBadSlot);
+    HIPCHK(c, hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(k_fill_i32, dim3(std::max(1, std::min(256, (P + kBlock - 1) / kBlock))), dim3(kBlock), 0, c->stream, dst, -1, (long long)P);
+    hipLaunchKernelGGL(k_placements, dim3(E), dim3(kPlaceBlock), 0, c->stream, c->g, N, E, K, 1 + N + E + J, P, slot_machine, (int)stride, dst, d_bad);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_flag + 1, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    return PSN_OK;
+}
+static int finish_placements(psn_ctx *c) {  // after the stream has drained
+    if (c->h_flag[1]) return fail(c, PSN_EINVAL, "slot arcs or task arcs are not where the layout puts them");
+    return PSN_OK;
+}
+static int run_placements(psn_ctx *c, const psn_layout *lay) {
+    int rc = check_place_layout(c, lay);
+    if (rc != PSN_OK) return rc;
+    const int E = lay->n_classes, P = lay->n_tasks;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->place_count != P || c->slot_stride != P || c->slot_classes != E) {
-        int rc;
         if ((rc = dalloc(c, &c->d_place, (size_t)P)) != PSN_OK) return rc;
         if ((rc = dalloc(c, &c->d_slot_machine, (size_t)E * (size_t)P)) != PSN_OK) return rc;
         c->place_count = P; c->slot_stride = P; c->slot_classes = E;
     }
-    hipLaunchKernelGGL(k_fill_i32, dim3(256), dim3(kBlock), 0, c->stream, c->d_place, -1, (long long)P);
-    hipLaunchKernelGGL(k_placements, dim3(E), dim3(kPlaceBlock), 0, c->stream, c->g, N, E, K, 1 + N + E + J, c->d_slot_machine, P, c->d_place);
-    HIPCHK(c, hipGetLastError());
-    return PSN_OK;
+    return launch_placements(c, lay, c->d_place, c->d_slot_machine, P);
 }
 
 int psn_get_placements(psn_ctx *c, const psn_layout *lay, int32_t *task_to_machine) {
@@ -1050,7 +1221,7 @@ int psn_get_placements(psn_ctx *c, const psn_layout *lay, int32_t *task_to_machi
     if (rc != PSN_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(task_to_machine, c->d_place, (size_t)lay->n_tasks * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return PSN_OK;
+    return finish_placements(c);
 }
 
 // Development aid (PSN_TRACE=1 in the environment at upload time): one record per sweep
@@ -1093,8 +1264,47 @@ int psn_get_placements_device(psn_ctx *c, const psn_layout *lay, void *dst_devic
     if (rc != PSN_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(dst_device, c->d_place, (size_t)lay->n_tasks * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return PSN_OK;
+    return finish_placements(c);
 }
+
+int psn_gather_placements(psn_ctx *const *ctxs, int32_t count, const psn_layout *layouts, int64_t stride, int32_t dst_device,
+                          void *dst) {
+    if (count < 0 || stride < 0 || (count > 0 && (!ctxs || !layouts || !dst))) return PSN_EINVAL;
+    for (int32_t i = 0; i < count; ++i) {
+        if (!ctxs[i]) return PSN_EINVAL;
+        if (layouts[i].n_tasks > stride) return fail(ctxs[i], PSN_EINVAL, "stride is smaller than the number of tasks");
+    }
+    int ndev = 0;
+    if (dst_device >= 0 && (hipGetDeviceCount(&ndev) != hipSuccess || dst_device >= ndev)) return PSN_EINVAL;
+    // extraction kernels of all contexts first (each on its own stream and device), then the copies
+    for (int32_t i = 0; i < count; ++i) {
+        const int rc = run_placements(ctxs[i], &layouts[i]);
+        if (rc != PSN_OK) return rc;
+    }
+    int first = PSN_OK;
+    for (int32_t i = 0; i < count; ++i) {
+        psn_ctx *c = ctxs[i];
+        const size_t bytes = (size_t)layouts[i].n_tasks * sizeof(int);
+        int32_t *row = static_cast<int32_t *>(dst) + (size_t)i * (size_t)stride;
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) {
+            if (dst_device < 0) e = hipMemcpyAsync(row, c->d_place, bytes, hipMemcpyDeviceToHost, c->stream);
+            else if (dst_device == c->device) e = hipMemcpyAsync(row, c->d_place, bytes, hipMemcpyDeviceToDevice, c->stream);
+            else e = hipMemcpyPeerAsync(row, dst_device, c->d_place, c->device, bytes, c->stream);
+        }
+        if (e != hipSuccess && first == PSN_OK) first = fail(c, PSN_EDEVICE, "psn_gather_placements: copy", e);
+    }
+    for (int32_t i = 0; i < count; ++i) {
+        psn_ctx *c = ctxs[i];
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess && first == PSN_OK) first = fail(c, PSN_EDEVICE, "psn_gather_placements: synchronize", e);
+        if (e == hipSuccess && first == PSN_OK) first = finish_placements(c);
+    }
+    return first;
+}
+
+uint64_t psn_debug_alloc_count(void) { return g_alloc_calls.load(); }
 
 int psn_placements_device_ptr(psn_ctx *c, void **dptr, int64_t *count) {
     if (!c || !dptr || !count) return fail(c, PSN_EINVAL, "null argument");

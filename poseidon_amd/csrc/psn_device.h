@@ -27,7 +27,7 @@ constexpr int PSN_EINFEASIBLE_DEV = -4;
 
 // tally slots (per wave, summed at the end of a solve)
 enum { kTallyScans = 0, kTallyPushes, kTallyRelabels, kTallyVisits, kTallyGuScans, kTallyGuRelax,
-       kTallySat, kTallyRounds, kTallyGuIters, kTallyN };
+       kTallySat, kTallyRounds, kTallyGuIters, kTallyGuSkips, kTallyN };
 
 // Device-resident loop control.  k_begin (one thread) and the first thread of k_gu_apply are the
 // only writers of the flags; sweep kernels read them and return at once when their
@@ -107,7 +107,8 @@ __global__ void k_tally_sum(DevGraph g, unsigned long long *out, int nslots);
 __global__ void k_eval_costs(DevGraph g, int E, int N, int K, const i64 *cap_cpu, const i64 *cap_mem, const i64 *used_cpu,
                              const i64 *used_mem, const i64 *req_cpu, const i64 *req_mem, const i64 *ec_arc_base, int *mcost,
                              int *mocap);
-__global__ void k_placements(DevGraph g, int N, int E, int K, int v_task0, int *slot_machine, int slot_stride, int *place);
+__global__ void k_placements(DevGraph g, int N, int E, int K, int v_task0, int n_tasks, int *slot_machine, int slot_stride, int *place,
+                             unsigned *bad);
 __global__ void k_fill_i32(int *p, int v, long long n);
 __global__ void k_scatter_caps(DevGraph g, long long count, const i64 *idx, const int *ncap, int *mocap);
 __global__ void k_clamp_flow(DevGraph g);

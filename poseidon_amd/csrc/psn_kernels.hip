@@ -1048,7 +1048,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                 bool anyc = false;
 #pragma unroll
                 for (int j = 0; j < 9; ++j) anyc |= rc9[j] > 0;
-                if (!__ballot(anyc)) continue;
+                if (!__ballot(anyc)) { t.c[kTallyGuSkips] += count9(a0, lim8, at, limt); continue; }  // only the 4-byte capacity was read
                 if (anyc) { load9(g.head, a0, lim8, at, limt, hd); load9(g.cost, a0, lim8, at, limt, cs); }
                 else {
 #pragma unroll
@@ -1177,8 +1177,8 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     i64 *dmax_slot = g.dmax_part + wave;
     unsigned long long *tslot = g.tally + (size_t)wave * kTallyN;  // this wave's work counters
     i64 dmax_seen = 0;
-    unsigned long long t_scans = 0, t_relax = 0, t_iters = 0;
-    if (lane == 0) { dmax_seen = *dmax_slot; t_scans = tslot[kTallyGuScans]; t_relax = tslot[kTallyGuRelax]; t_iters = tslot[kTallyGuIters]; }
+    unsigned long long t_scans = 0, t_relax = 0, t_iters = 0, t_skips = 0;
+    if (lane == 0) { dmax_seen = *dmax_slot; t_scans = tslot[kTallyGuScans]; t_relax = tslot[kTallyGuRelax]; t_iters = tslot[kTallyGuIters]; t_skips = tslot[kTallyGuSkips]; }
     // second halves
     i64 hub_gain = 0;
     if (hub_cand && hub_nd < dist_of(hub_seen)) {
@@ -1200,8 +1200,10 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     // raising one word serialise at the memory side); k_gu_apply folds the slots.
     wmax = wave_max(wmax > hub_gain ? wmax : hub_gain);
     const unsigned n_scans = wave_sum_u32(t.c[kTallyGuScans]), n_relax = wave_sum_u32(t.c[kTallyGuRelax]), n_iters = wave_sum_u32(t.c[kTallyGuIters]);
+    const unsigned n_skips = wave_sum_u32(t.c[kTallyGuSkips]);
     if (lane == 0) {
         if (wmax > dmax_seen) *dmax_slot = wmax;
+        if (n_skips) tslot[kTallyGuSkips] = t_skips + n_skips;
         if (n_scans) tslot[kTallyGuScans] = t_scans + n_scans;
         if (n_relax) tslot[kTallyGuRelax] = t_relax + n_relax;
         if (n_iters) tslot[kTallyGuIters] = t_iters + n_iters;
@@ -1406,11 +1408,32 @@ struct SlotCosts {
         if (r >= c) { r -= c; ++q; }
     }
 };
+// Layout check of the slot block, run as a pass of its own before the cost kernel writes
+// anything: the K reverse arcs of every (machine, class) pair must sit class-major, slot-minor
+// at the start of the machine's row and pair up with the K forward arcs at ec_arc_base[e] + m * K.
+// bad[0] counts the pairs that do not; the cost kernel returns without a write when it is nonzero.
+__global__ __launch_bounds__(kBlock) void k_check_slot_layout(DevGraph g, int E, int N, int K, const i64 *ec_arc_base, unsigned *bad) {
+    const long long groups = (long long)E * N;
+    unsigned mine = 0;
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < groups; i += (long long)gridDim.x * kBlock) {
+        const int e = (int)(i % E), m = (int)(i / E);
+        const unsigned a0 = (unsigned)(ec_arc_base[e] + (i64)m * K);
+        const unsigned r0 = g.row[1 + m] + (unsigned)e * (unsigned)K;
+        bool ok = r0 + (unsigned)K <= g.row[2 + m] && a0 + (unsigned)K <= g.m2;
+        for (int k = 0; ok && k < K; ++k) ok = (unsigned)g.rev[r0 + k] == a0 + (unsigned)k && (unsigned)g.rev[a0 + k] == r0 + (unsigned)k;
+        mine += !ok;
+    }
+    if (__ballot(mine != 0)) {
+        mine = wave_sum_u32(mine);
+        if (lane_id() == 0) aadd32(bad, mine);
+    }
+}
 __global__ __launch_bounds__(kBlock) void k_eval_costs(DevGraph g, int E, int N, int K, const i64 *cap_cpu, const i64 *cap_mem,
                                                        const i64 *used_cpu, const i64 *used_mem, const i64 *req_cpu,
                                                        const i64 *req_mem, const i64 *ec_arc_base, int *mcost, int *mocap,
-                                                       int keep_flow, const unsigned *allow, int allow_words, unsigned *bad_layout) {
+                                                       int keep_flow, const unsigned *allow, int allow_words, const unsigned *bad_layout) {
     const long long groups = (long long)E * N;
+    if (*bad_layout) return;  // the layout pass found pairs that do not line up: nothing is written
     for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < 2 * groups; i += (long long)gridDim.x * kBlock) {
         const bool fwd = i < groups;
         const long long gi = fwd ? i : i - groups;
@@ -1423,7 +1446,6 @@ __global__ __launch_bounds__(kBlock) void k_eval_costs(DevGraph g, int E, int N,
         if (allow && !((allow[(size_t)e * allow_words + (m >> 5)] >> (m & 31)) & 1u)) fit = 0;  // selector mismatch: no capacity
         const unsigned a0 = (unsigned)(ec_arc_base[e] + (i64)m * K);
         const unsigned r0 = g.row[1 + m] + (unsigned)e * (unsigned)K;
-        if (!fwd && (r0 + (unsigned)K > g.row[2 + m] || (unsigned)g.rev[r0] != a0)) { aadd32(bad_layout, 1u); continue; }
         SlotCosts sc(uc, rc, cc), sm(um, rm, cm);
         const unsigned b0 = fwd ? a0 : r0;  // first of this thread's K entries
         if (K == 8) {  // the usual shape: eight slots, written as two 16-byte stores per array
@@ -1494,8 +1516,10 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned x, unsigned *lds, u
     total = tot;
     return off + incl - x;
 }
-__global__ __launch_bounds__(kPlaceBlock) void k_placements(DevGraph g, int N, int E, int K, int v_task0, int *slot_machine,
-                                                            int slot_stride, int *place) {
+// bad[0] counts arcs whose head is not where the layout says it should be (a slot arc that does
+// not end at a machine, a reverse arc that does not end at a task); nothing is written for them.
+__global__ __launch_bounds__(kPlaceBlock) void k_placements(DevGraph g, int N, int E, int K, int v_task0, int n_tasks, int *slot_machine,
+                                                            int slot_stride, int *place, unsigned *bad) {
     __shared__ unsigned lds[kPlaceBlock / 64];
     const int e = blockIdx.x;
     if (e >= E) return;
@@ -1523,7 +1547,11 @@ __global__ __launch_bounds__(kPlaceBlock) void k_placements(DevGraph g, int N, i
         if (f) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                for (int x = 0; x < fl[j]; ++x, ++pos) if (pos < (unsigned)slot_stride) sm[pos] = g.head[a0 + j] - 1;
+                if (fl[j]) {
+                    const int mch = g.head[a0 + j] - 1;
+                    if ((unsigned)mch >= (unsigned)N) { aadd32(bad, 1u); pos += (unsigned)fl[j]; continue; }
+                    for (int x = 0; x < fl[j]; ++x, ++pos) if (pos < (unsigned)slot_stride) sm[pos] = mch;
+                }
         }
         run += tot;
     }
@@ -1536,7 +1564,11 @@ __global__ __launch_bounds__(kPlaceBlock) void k_placements(DevGraph g, int N, i
         if (a < t1) f = g.cap[a] > 0 ? 1u : 0u;  // residual on the reverse arc == task routed here
         unsigned tot;
         unsigned pos = run + block_excl_scan(f, lds, tot);
-        if (f) place[g.head[a] - v_task0] = pos < units ? sm[pos] : -1;
+        if (f) {
+            const int tk = g.head[a] - v_task0;
+            if ((unsigned)tk >= (unsigned)n_tasks) aadd32(bad, 1u);
+            else place[tk] = pos < units && pos < (unsigned)slot_stride ? sm[pos] : -1;
+        }
         run += tot;
     }
 }

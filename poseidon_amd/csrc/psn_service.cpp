@@ -44,6 +44,8 @@ struct Machine {
     std::string uuid;
     std::map<std::string, std::string> labels;
     i64 cap_cpu = 0, cap_mem = 0, used_cpu = 0, used_mem = 0;
+    i64 committed_cpu = 0, committed_mem = 0;  // requests of the tasks running here (keep-running mode)
+    int running = 0;                           // how many they are: each holds one of the machine's slots
     bool live = false;
     uint32_t gen = 0;  // bumped whenever the index changes hands
 };
@@ -72,6 +74,7 @@ struct Task {
     i64 place_class = -1, place_job = -1;  // arc indices of its reverse places
     int machine = -1;            // placement after the last round
     uint32_t machine_gen = 0;
+    bool pinned = false;         // running on `machine` and therefore outside the network (keep-running mode)
     i64 cpu = 0, ram = 0;
 };
 struct Delta { uint64_t uid; int32_t type; int machine; };
@@ -119,6 +122,9 @@ struct psn_svc {
     std::vector<int32_t> new_sources;
     bool reprice = false;
     bool settled = false;  // the last round ran to its end and nothing has been queued since
+    bool orphans = false;  // a machine went away: tasks pinned to it have to come back into the network
+    i64 attached = 0;      // tasks in the network
+    i64 pinned_total = 0;  // tasks running (outside the network)
     // results
     std::vector<Delta> deltas;
     psn_svc_stats st{};
@@ -176,6 +182,7 @@ struct psn_svc {
         set_supply(vt, 1);
         set_supply(0, supply[0] - 1);
         if (resident) new_sources.push_back(vt);
+        ++attached;
         return true;
     }
     void detach(Task &t) {
@@ -197,6 +204,61 @@ struct psn_svc {
         free_slots.push_back(t.slot);
         t.slot = -1;
         t.place_class = t.place_job = -1;
+        --attached;
+    }
+
+    // ---------------------------------------------------------------- running tasks (keep-running mode)
+    bool keep_running() const { return cfg.reschedule_running == 0; }
+    bool on_its_machine(const Task &t) const {
+        return t.machine >= 0 && (size_t)t.machine < machines.size() && machines[(size_t)t.machine].gen == t.machine_gen;
+    }
+    int sink_capacity(int m) const {
+        if ((size_t)m >= machines.size() || !machines[(size_t)m].live) return 0;
+        return std::max(0, cfg.slots_per_machine - machines[(size_t)m].running);
+    }
+    void account(int m, i64 dcpu, i64 dmem, int drunning) {
+        Machine &mc = machines[(size_t)m];
+        mc.committed_cpu += dcpu; mc.committed_mem += dmem; mc.running += drunning;
+        if (laid_out && !need_layout && m < N) {
+            if (drunning) set_cap(machine_sink_arc(m), sink_capacity(m));
+            reprice = true;
+        }
+    }
+    // The task starts running on machine m: it leaves the network and its request counts as usage there.
+    void pin(Task &t, int m) {
+        if (t.slot >= 0) {
+            if (need_layout) {  // the network is about to be laid out again: no point in editing it
+                slot_uid[(size_t)t.slot] = 0; slot_used[(size_t)t.slot] = 0; slot_task[(size_t)t.slot] = nullptr;
+                t.slot = -1; t.place_class = t.place_job = -1;
+                --attached;
+            } else {
+                detach(t);
+            }
+        }
+        t.pinned = true;
+        ++pinned_total;
+        account(m, t.cpu, t.ram, 1);
+    }
+    // The task stops running (it left, or is about to be described anew).
+    void unpin(Task &t) {
+        if (!t.pinned) return;
+        t.pinned = false;
+        --pinned_total;
+        if (on_its_machine(t)) account(t.machine, -t.cpu, -t.ram, -1);
+    }
+
+    // Tasks that ran on a machine that went away are pending again: back into the network.
+    void readmit_orphans() {
+        if (!orphans) return;
+        for (auto &kv : tasks) {
+            Task &t = kv.second;
+            if (!t.pinned || on_its_machine(t)) continue;
+            t.pinned = false;
+            --pinned_total;
+            t.machine = -1;
+            if (laid_out && !need_layout && !attach(t)) need_layout = true;
+        }
+        orphans = false;
     }
 
     // ---------------------------------------------------------------- entity tables
@@ -308,7 +370,7 @@ struct psn_svc {
         const double t0 = now_ms();
         K = cfg.k_slots;
         i64 live_tasks = 0;
-        for (auto &kv : tasks) if (kv.second.state == kRunnable) ++live_tasks;
+        for (auto &kv : tasks) if (kv.second.state == kRunnable && !kv.second.pinned) ++live_tasks;
         auto grown = [](i64 have, i64 floor_) { return (int)std::max<i64>(floor_, have + have / 4 + 1); };
         N = grown((i64)machines.size(), std::max(cfg.max_machines, 1));
         E = std::max<int>(cfg.max_classes, (int)((classes.size() + 63) / 64 * 64));
@@ -322,7 +384,7 @@ struct psn_svc {
         // members per class / job among runnable tasks
         std::vector<i64> cnt_e((size_t)E, 0), cnt_j((size_t)J, 0);
         for (auto &kv : tasks)
-            if (kv.second.state == kRunnable) { ++cnt_e[(size_t)kv.second.cls]; ++cnt_j[(size_t)kv.second.job]; }
+            if (kv.second.state == kRunnable && !kv.second.pinned) { ++cnt_e[(size_t)kv.second.cls]; ++cnt_j[(size_t)kv.second.job]; }
         const i64 avg_job = jobs.empty() ? 16 : std::max<i64>(16, live_tasks / (i64)std::max<size_t>(1, job_by_uuid.size()));
         row_off.assign((size_t)n + 1, 0);
         row_off[1] = (i64)N + J;
@@ -345,6 +407,7 @@ struct psn_svc {
         resident = false;  // edits below go to the mirror only
         dirty_arcs.clear(); cap_updates.clear(); dirty_supply.clear(); new_sources.clear();
         laid_out = true;
+        attached = 0;
         auto pair_up = [&](i64 a, i64 r, int to, int from, int cp, int cs) {
             head[(size_t)a] = to; cap[(size_t)a] = cp; cost[(size_t)a] = cs; rev[(size_t)a] = (int32_t)r;
             head[(size_t)r] = from; cap[(size_t)r] = 0; cost[(size_t)r] = -cs; rev[(size_t)r] = (int32_t)a;
@@ -377,8 +440,7 @@ struct psn_svc {
             if ((size_t)j < jobs.size()) jobs[(size_t)j].pool = spare_job_pool(j);
         }
         for (int m = 0; m < N; ++m) {
-            const bool live = (size_t)m < machines.size() && machines[(size_t)m].live;
-            pair_up(row_off[(size_t)(1 + m)] + (i64)E * K, row_off[0] + m, 0, 1 + m, live ? cfg.slots_per_machine : 0, 0);
+            pair_up(row_off[(size_t)(1 + m)] + (i64)E * K, row_off[0] + m, 0, 1 + m, sink_capacity(m), 0);
         }
         slot_uid.assign((size_t)P, 0);
         slot_used.assign((size_t)P, 0);
@@ -393,7 +455,7 @@ struct psn_svc {
         // runnable tasks in uid order, so that a layout is a function of the state alone
         std::vector<uint64_t> uids;
         uids.reserve(tasks.size());
-        for (auto &kv : tasks) { kv.second.slot = -1; if (kv.second.state == kRunnable) uids.push_back(kv.first); }
+        for (auto &kv : tasks) { kv.second.slot = -1; if (kv.second.state == kRunnable && !kv.second.pinned) uids.push_back(kv.first); }
         std::sort(uids.begin(), uids.end());
         for (uint64_t u : uids)
             if (!attach(tasks[u])) return fail(PSN_EINVAL, "internal: fresh layout without room");
@@ -419,7 +481,9 @@ struct psn_svc {
             const Machine &mc = machines[m];
             if (!mc.live) continue;
             cc[m] = mc.cap_cpu; cm[m] = mc.cap_mem;
-            uc[m] = std::min(mc.used_cpu, mc.cap_cpu); um[m] = std::min(mc.used_mem, mc.cap_mem);
+            // usage = what the statistics report for things the service does not manage + the requests
+            // of the tasks it has running there
+            uc[m] = std::min(mc.used_cpu + mc.committed_cpu, mc.cap_cpu); um[m] = std::min(mc.used_mem + mc.committed_mem, mc.cap_mem);
         }
         rc.assign((size_t)E, 1); rm.assign((size_t)E, 1);
         for (size_t e = 0; e < classes.size() && e < (size_t)E; ++e) { rc[e] = classes[e].cpu; rm[e] = classes[e].ram; }
@@ -437,7 +501,8 @@ int add_runnable(psn_svc *s, Task &t) {
 }
 void drop_runnable(psn_svc *s, Task &t) {
     --s->runnable;
-    if (s->laid_out && t.slot >= 0) s->detach(t);
+    if (t.pinned) s->unpin(t);
+    else if (s->laid_out && t.slot >= 0) s->detach(t);
     t.slot = -1;
 }
 bool bad_uuid(const char *u) { return !u || !*u || std::strlen(u) > 36; }
@@ -523,6 +588,12 @@ int psn_svc_task_updated(psn_svc *s, uint64_t uid, const char *job_uuid, int64_t
     cpu = std::max<i64>(cpu, 1);
     ram = std::max<i64>(ram, 1);
     if (cpu == t.cpu && ram == t.ram) return PSN_TASK_UPDATED_OK;
+    if (t.pinned) {  // running: only what it holds on its machine changes
+        if (s->on_its_machine(t)) s->account(t.machine, cpu - t.cpu, ram - t.ram, 0);
+        t.cpu = cpu; t.ram = ram;
+        t.cls = s->class_of(cpu, ram, s->classes[(size_t)t.cls].selectors);
+        return PSN_TASK_UPDATED_OK;
+    }
     const bool in_network = t.state == kRunnable;
     if (in_network) drop_runnable(s, t);
     t.cpu = cpu; t.ram = ram;
@@ -565,9 +636,10 @@ int psn_svc_node_added(psn_svc *s, const char *uuid, int64_t cpu, int64_t ram) {
     else { m = (int)s->machines.size(); s->machines.emplace_back(); }
     Machine &mc = s->machines[(size_t)m];
     mc.uuid = uuid; mc.cap_cpu = cpu; mc.cap_mem = ram; mc.used_cpu = mc.used_mem = 0; mc.live = true; ++mc.gen;
+    mc.committed_cpu = mc.committed_mem = 0; mc.running = 0;
     s->machine_by_uuid[uuid] = m;
     mc.labels.clear();
-    if (s->laid_out && m < s->N) { s->set_cap(s->machine_sink_arc(m), s->cfg.slots_per_machine); s->reprice = true; s->mask_machine(m); }
+    if (s->laid_out && m < s->N) { s->set_cap(s->machine_sink_arc(m), s->sink_capacity(m)); s->reprice = true; s->mask_machine(m); }
     else s->need_layout = true;
     return PSN_NODE_ADDED_OK;
 }
@@ -600,6 +672,8 @@ static int node_leaves(psn_svc *s, const char *uuid, int ok_code) {
     mc.live = false;
     mc.uuid.clear();
     ++mc.gen;  // placements on it no longer count as "previous machine"
+    if (mc.running > 0) s->orphans = true;  // the tasks that ran here are pending again
+    mc.committed_cpu = mc.committed_mem = 0; mc.running = 0;
     s->machine_by_uuid.erase(it);
     s->free_machines.push_back(m);
     mc.labels.clear();
@@ -628,6 +702,7 @@ int psn_svc_node_labels(psn_svc *s, const char *uuid, const char *const *keys, c
 
 int psn_svc_export_mask(psn_svc *s, uint32_t *mask) {
     if (!s || !mask) return PSN_EINVAL;
+    s->readmit_orphans();
     if (!s->laid_out || s->need_layout) { const int rc = s->layout(); if (rc != PSN_OK) return rc; }
     std::copy(s->allow.begin(), s->allow.end(), mask);
     return PSN_OK;
@@ -640,6 +715,7 @@ int psn_svc_check(const psn_svc *s) {
 
 int psn_svc_network_size(psn_svc *s, psn_layout *lay, int32_t *n, int64_t *m2) {
     if (!s) return PSN_EINVAL;
+    s->readmit_orphans();
     if (!s->laid_out || s->need_layout) { const int rc = s->layout(); if (rc != PSN_OK) return rc; }
     if (lay) *lay = s->lay;
     if (n) *n = s->n;
@@ -651,6 +727,7 @@ int psn_svc_export_network(psn_svc *s, int64_t *row_off, int32_t *head, int32_t 
                            int64_t *ec_arc_base, int64_t *cap_cpu, int64_t *cap_mem, int64_t *used_cpu, int64_t *used_mem,
                            int64_t *req_cpu, int64_t *req_mem) {
     if (!s) return PSN_EINVAL;
+    s->readmit_orphans();
     if (!s->laid_out || s->need_layout) { const int rc = s->layout(); if (rc != PSN_OK) return rc; }
     auto put64 = [](int64_t *dst, const std::vector<i64> &v) { if (dst) std::copy(v.begin(), v.end(), dst); };
     auto put32 = [](int32_t *dst, const std::vector<int32_t> &v) { if (dst) std::copy(v.begin(), v.end(), dst); };
@@ -669,7 +746,17 @@ int64_t psn_svc_schedule(psn_svc *s) {
     s->st.build_ms = s->st.upload_ms = s->st.update_ms = s->st.solve_ms = s->st.extract_ms = 0;
     s->st.patched_arcs = s->st.cap_updates = s->st.supply_updates = 0;
     s->deltas.clear();
+    s->st.tasks_deferred = 0;
     int rc;
+    s->readmit_orphans();
+    // Keep-running mode with nothing pending: there is nothing to decide, whatever is queued (and a
+    // layout that is due) waits for the round that has something to place.
+    if (s->keep_running() && s->runnable == s->pinned_total && !s->cfg.emit_noop) {
+        s->st.last_round_warm = 1;
+        ++s->st.warm_rounds;
+        s->st.tasks_placed = 0;
+        return 0;
+    }
     if (!s->laid_out || s->need_layout) { if ((rc = s->layout()) != PSN_OK) return rc; }
     // Nothing was submitted, removed, re-priced or re-labelled since a round that ran to its end:
     // the resident optimum still stands and there is nothing to report (Poseidon calls Schedule
@@ -816,11 +903,34 @@ int64_t psn_svc_schedule(psn_svc *s) {
                 done[i] = 1;
             }
     }
+    // Keep-running mode: a placement is admitted only if the task's request still fits next to what
+    // the machine already holds, tasks admitted earlier in this round included.  One class never
+    // over-commits a machine (the slot arcs that do not fit have no capacity), two classes placed on
+    // one machine in the same round can; the task that does not fit stays pending and is priced
+    // against the new usage next round.
+    const bool keep = s->keep_running();
+    std::vector<std::pair<Task *, int>> to_pin;
+    std::vector<i64> free_cpu, free_mem;
+    std::vector<int> free_slot;
+    if (keep) {
+        free_cpu.resize(s->machines.size()); free_mem.resize(s->machines.size()); free_slot.resize(s->machines.size());
+        for (size_t m = 0; m < s->machines.size(); ++m) {
+            const Machine &mc = s->machines[m];
+            free_cpu[m] = mc.cap_cpu - std::min(mc.used_cpu + mc.committed_cpu, mc.cap_cpu);
+            free_mem[m] = mc.cap_mem - std::min(mc.used_mem + mc.committed_mem, mc.cap_mem);
+            free_slot[m] = s->sink_capacity((int)m);
+        }
+    }
     for (int t = 0; t < s->P; ++t) {
         if (!s->slot_used[(size_t)t]) continue;
         Task &tk = *s->slot_task[(size_t)t];
-        const bool had = tk.machine >= 0 && (size_t)tk.machine < s->machines.size() && s->machines[(size_t)tk.machine].gen == tk.machine_gen;
-        const int now = final_place[(size_t)t];
+        const bool had = s->on_its_machine(tk);
+        int now = final_place[(size_t)t];
+        if (keep && now >= 0) {
+            const size_t m = (size_t)now;
+            if (tk.cpu > free_cpu[m] || tk.ram > free_mem[m] || free_slot[m] <= 0) { now = -1; ++s->st.tasks_deferred; }
+            else { free_cpu[m] -= tk.cpu; free_mem[m] -= tk.ram; --free_slot[m]; to_pin.emplace_back(&tk, now); }
+        }
         int type = PSN_DELTA_NOOP;
         if (!had && now >= 0) type = PSN_DELTA_PLACE;
         else if (had && now < 0) type = PSN_DELTA_PREEMPT;
@@ -830,8 +940,14 @@ int64_t psn_svc_schedule(psn_svc *s) {
         tk.machine_gen = now >= 0 ? s->machines[(size_t)now].gen : 0;
         if (now >= 0) ++placed;
     }
+    if (keep && !to_pin.empty()) {
+        // most of the network leaving at once (a first round): lay the rest out afresh instead of parking arc by arc
+        if ((i64)to_pin.size() * 4 > s->attached) s->need_layout = true;
+        for (auto &pr : to_pin) s->pin(*pr.first, pr.second);
+    }
     s->st.extract_ms = now_ms() - t0;
     s->st.tasks_placed = placed;
+    s->st.tasks_running = s->pinned_total;
     s->st.tasks_runnable = s->runnable;
     s->st.machines_live = (i64)s->machine_by_uuid.size();
     s->st.n = s->n;
@@ -860,6 +976,7 @@ int psn_svc_get_stats(const psn_svc *s, psn_svc_stats *out) {
     if (!s || !out) return PSN_EINVAL;
     *out = s->st;
     out->tasks_runnable = s->runnable;
+    out->tasks_running = s->pinned_total;
     out->machines_live = (i64)s->machine_by_uuid.size();
     return PSN_OK;
 }

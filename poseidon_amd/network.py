@@ -96,3 +96,66 @@ def build_network(cl: Cluster) -> Network:
                                      _vp(cl.task_job), _vp(net.row_off), _vp(net.head), _vp(net.cap),
                                      _vp(net.cost), _vp(net.rev), _vp(net.supply), _vp(net.ec_arc_base)))
     return net
+
+
+# ---- churn rounds of the incremental configuration (psn-synth-v1, configs[3])
+_MAGIC = 0x506F736569646F6E
+_GAMMA = 0x9E3779B97F4A7C15
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+
+def _splitmix64(seed: int):
+    """Generator of splitmix64 outputs started at `seed`."""
+    x = seed & _M64
+    while True:
+        x = (x + _GAMMA) & _M64
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        yield z ^ (z >> 31)
+
+
+@dataclasses.dataclass
+class ChurnRound:
+    """What one round of churn does to a cluster: tasks that leave and what replaces them, machines
+    that report new usage, machines that go away (indices into the cluster's arrays)."""
+    tasks_replaced: np.ndarray
+    new_class: np.ndarray
+    new_job: np.ndarray
+    machines_restat: np.ndarray
+    new_used_cpu: np.ndarray
+    new_used_mem: np.ndarray
+    machines_out: np.ndarray
+
+
+def churn_round(cl: Cluster, config_id: int, seed: int, round_no: int = 1) -> ChurnRound:
+    """5 % of the tasks leave and as many arrive with fresh (class, job) draws, 5 % of the machines
+    report fresh usage (0..600 permille of capacity), 1 % of the machines go away.  Stream seed
+    MAGIC ^ (config_id << 32) ^ seed ^ (0xC3 << 56) ^ (round_no << 40); draws in that order, repeats
+    among the chosen tasks / machines rejected."""
+    N, P, J, E = cl.layout.n_machines, cl.layout.n_tasks, cl.layout.n_jobs, cl.layout.n_classes
+    g = _splitmix64(_MAGIC ^ (config_id << 32) ^ seed ^ (0xC3 << 56) ^ (round_no << 40))
+
+    def distinct(count, modulus):
+        seen, out = set(), []
+        while len(out) < count:
+            x = next(g) % modulus
+            if x not in seen:
+                seen.add(x)
+                out.append(x)
+        return np.array(out, dtype=np.int64)
+
+    tasks = distinct(P // 20, P)
+    new_class = np.empty(tasks.shape[0], np.int32)
+    new_job = np.empty(tasks.shape[0], np.int32)
+    for i in range(tasks.shape[0]):
+        new_class[i] = next(g) % E
+        new_job[i] = next(g) % J
+    mach = distinct(N // 20, N)
+    nuc = np.empty(mach.shape[0], np.int64)
+    num = np.empty(mach.shape[0], np.int64)
+    for i, m in enumerate(mach):
+        nuc[i] = int(cl.cap_cpu[m]) * (next(g) % 601) // 1000
+        num[i] = int(cl.cap_mem[m]) * (next(g) % 601) // 1000
+    out = distinct(N // 100, N)
+    return ChurnRound(tasks, new_class, new_job, mach, nuc, num, out)

@@ -22,7 +22,7 @@ class SvcConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_machines", C.c_int32), ("max_tasks", C.c_int32),
                 ("max_jobs", C.c_int32), ("max_classes", C.c_int32), ("k_slots", C.c_int32),
                 ("slots_per_machine", C.c_int32), ("unsched_cost", C.c_int32), ("emit_noop", C.c_int32),
-                ("solver", _lib.Config)]
+                ("reschedule_running", C.c_int32), ("solver", _lib.Config)]
 
 
 class SvcStats(C.Structure):
@@ -32,7 +32,8 @@ class SvcStats(C.Structure):
                 ("n", C.c_int64), ("m2", C.c_int64),
                 ("build_ms", C.c_double), ("upload_ms", C.c_double), ("update_ms", C.c_double),
                 ("solve_ms", C.c_double), ("extract_ms", C.c_double),
-                ("total_cost", C.c_int64), ("last_round_warm", C.c_int32)]
+                ("total_cost", C.c_int64), ("last_round_warm", C.c_int32),
+                ("tasks_running", C.c_int64), ("tasks_deferred", C.c_int64)]
 
 
 class Selector(C.Structure):  # include/psn_service.h psn_selector
@@ -93,11 +94,13 @@ class SchedulerService:
     host (no Schedule), any other value binds the solver to that GPU."""
 
     def __init__(self, device: int = 0, max_machines: int = 0, max_tasks: int = 0, max_jobs: int = 0,
-                 emit_noop: bool = False, slots_per_machine: int = 0, unsched_cost: int = 0):
+                 emit_noop: bool = False, slots_per_machine: int = 0, unsched_cost: int = 0,
+                 reschedule_running: bool = False):
         self._lib = _lib.load_library()
         _bind(self._lib)
         cfg = SvcConfig(device=device, max_machines=max_machines, max_tasks=max_tasks, max_jobs=max_jobs,
-                        emit_noop=int(emit_noop), slots_per_machine=slots_per_machine, unsched_cost=unsched_cost)
+                        emit_noop=int(emit_noop), slots_per_machine=slots_per_machine, unsched_cost=unsched_cost,
+                        reschedule_running=int(reschedule_running))
         self._svc = C.c_void_p(None)
         rc = self._lib.psn_svc_create(C.byref(cfg), C.byref(self._svc))
         if rc != _lib.PSN_OK:

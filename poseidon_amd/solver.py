@@ -27,6 +27,7 @@ class SolveResult:
     global_updates: int
     launches: int
     solve_ms: float
+    gu_arc_skips: int = 0
 
     @property
     def algorithmic_bytes(self) -> int:

@@ -92,3 +92,17 @@ def test_no_gpu_fails_loudly():
     with pytest.raises(pa.PsnError) as ei:
         pa.Solver()
     assert ei.value.code == _lib.PSN_EDEVICE
+
+
+def test_churn_generator_matches_the_oracle_spec():
+    """The churn rounds the benchmark feeds to the service are drawn by the package's own generator;
+    it must produce exactly what the oracle's restatement of the spec produces."""
+    from poseidon_amd import network
+    for cfg, seed, rnd in [(0, 1, 1), (0, 3, 2), (1, 2, 1)]:
+        cl = pa.synth_cluster(cfg, seed)
+        ch = network.churn_round(cl, cfg, seed, rnd)
+        _, och = synth.churn(synth.make_cluster(cfg, seed), cfg, seed, rnd)
+        for a, b in [(ch.tasks_replaced, och.pods_replaced), (ch.new_class, och.new_shape), (ch.new_job, och.new_job),
+                     (ch.machines_restat, och.machines_restat), (ch.new_used_cpu, och.new_used_cpu),
+                     (ch.new_used_mem, och.new_used_mem), (ch.machines_out, och.machines_out)]:
+            assert np.array_equal(a, b)

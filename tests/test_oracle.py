@@ -125,3 +125,33 @@ def test_infeasible_and_trivial():
     g = synth.graph_from_arcs(3, [0, 1], [1, 2], [2, 2], [1, 1], [0, 0, 0])
     assert capi.ssp(g)[:2] == (0, 0)
     assert capi.cost_scaling(g)[:2] == (0, 0)
+
+
+def test_tuned_baseline_variant_agrees_with_the_plain_oracle():
+    """The timed CPU baseline has a tuned variant (first epsilon from the 90th-percentile cost,
+    alpha 16, price refinement); it must reach the same optimum as the plain variant, on the
+    synthetic family and on random graphs with negative costs (where the percentile start is off)."""
+    rng = np.random.default_rng(11)
+    graphs = [synth.build_graph(synth.make_cluster(0, s)) for s in (1, 2)]
+    for _ in range(30):
+        n = int(rng.integers(2, 60))
+        m = int(rng.integers(1, 6 * n))
+        tail, head = rng.integers(0, n, m), rng.integers(0, n, m)
+        keep = tail != head
+        tail, head = tail[keep], head[keep]
+        cap = rng.integers(1, 6, tail.shape[0])
+        pi = rng.integers(0, 10, n)
+        cost = rng.integers(0, 30, tail.shape[0]) + pi[tail] - pi[head]
+        f = rng.integers(0, cap + 1)
+        supply = np.zeros(n, np.int64)
+        np.add.at(supply, tail, f)
+        np.add.at(supply, head, -f)
+        graphs.append(synth.graph_from_arcs(n, tail, head, cap, cost, supply))
+    for g in graphs:
+        want = None
+        for kw in capi.BASELINE_VARIANTS.values():
+            rc, tc, cap, price, _ = capi.cost_scaling(g, **kw)
+            assert rc == 0
+            assert capi.check(g, cap, price)[:2] == (0, tc)
+            want = tc if want is None else want
+            assert tc == want

@@ -48,7 +48,7 @@ def machine_index(uuid):
 @pytest.mark.parametrize("cfg,seed", [(0, 1), (0, 2), (1, 1)])
 def test_schedule_rounds_cold_then_warm(cfg, seed):
     cl = synth.make_cluster(cfg, seed)
-    with pa.SchedulerService(device=0) as s:
+    with pa.SchedulerService(device=0, reschedule_running=True) as s:
         assert s.Check()
         uids = feed_cluster(s, cl)
         deltas = s.Schedule()
@@ -98,7 +98,7 @@ def test_churn_round_at_full_scale():
     """The incremental configuration at the 10k-machine / 100k-pod size: one cold round, one churn
     round applied in place and warm-started; both optima equal the oracle's from-scratch optimum."""
     cl = synth.make_cluster(2, 1)
-    with pa.SchedulerService(device=0) as s:
+    with pa.SchedulerService(device=0, reschedule_running=True) as s:
         uids = feed_cluster(s, cl)
         deltas = s.Schedule()
         st = s.stats()
@@ -118,7 +118,7 @@ def test_warm_round_moves_few_tasks():
     """A warm round after 5 % churn must not reshuffle the cluster: deltas stay a small
     multiple of what changed."""
     cl = synth.make_cluster(1, 2)
-    with pa.SchedulerService(device=0) as s:
+    with pa.SchedulerService(device=0, reschedule_running=True) as s:
         uids = feed_cluster(s, cl)
         s.Schedule()
         cl2, ch = synth.churn(cl, 1, 2, 1)
@@ -131,7 +131,7 @@ def test_warm_round_moves_few_tasks():
 
 def test_node_failure_and_task_lifecycle():
     cl = synth.make_cluster(0, 3)
-    with pa.SchedulerService(device=0, emit_noop=True) as s:
+    with pa.SchedulerService(device=0, emit_noop=True, reschedule_running=True) as s:
         uids = feed_cluster(s, cl)
         deltas = s.Schedule()
         assert len(deltas) == cl.n_pods  # with emit_noop every runnable task is reported
@@ -233,24 +233,24 @@ def test_node_selector_end_to_end():
             == TR.TASK_SUBMITTED_OK
         assert s.TaskSubmitted(101, job_uuid(1), 500, 1 << 20, selectors=[(IN_SET, "kubernetes.io/hostname", ["node-9"])]) \
             == TR.TASK_SUBMITTED_OK
+        g, _ = exported_graph(s)  # what this round solves (placed tasks leave the network afterwards)
+        rc, tc, _, _, _ = capi.cost_scaling(g)
         deltas = {d.task_id: d for d in s.Schedule()}
+        assert rc == 0 and tc == s.stats().total_cost
         assert deltas[100].type == CT.PLACE and machine_index(deltas[100].resource_id) == 4
         assert 101 not in deltas and s.task_placement(101) == ""
         assert len(deltas) == 21
-        g, _ = exported_graph(s)
-        rc, tc, _, _, _ = capi.cost_scaling(g)
-        assert rc == 0 and tc == s.stats().total_cost
         # the label appears on a node later: the pending pod is placed by a warm round
         assert s.NodeLabels(machine_uuid(2), {"kubernetes.io/hostname": "node-9"}) == NR.NODE_UPDATED_OK
         deltas = {d.task_id: d for d in s.Schedule()}
-        assert s.stats().last_round_warm == 1
+        assert list(deltas) == [101], "the tasks that are running stay where they are and are not reported again"
         assert deltas[101].type == CT.PLACE and machine_index(deltas[101].resource_id) == 2
         # an over-committed pod (request larger than any node) stays unscheduled (:310-408)
         assert s.TaskSubmitted(102, job_uuid(2), 64000, 1 << 20) == TR.TASK_SUBMITTED_OK
-        assert all(d.task_id != 102 for d in s.Schedule())
         g, _ = exported_graph(s)
         rc, tc, _, _, _ = capi.cost_scaling(g)
-        assert rc == 0 and tc == s.stats().total_cost
+        assert s.Schedule() == []
+        assert rc == 0 and tc == s.stats().total_cost == synth.C_UNSCHED
 
 
 @pytest.mark.parametrize("seed", [21, 22])
@@ -262,7 +262,7 @@ def test_random_rpc_sequences_scheduled_on_the_gpu(seed):
     rng = np.random.default_rng(seed)
     shapes, st = rpc_shapes(), RpcModel()
     where = {}
-    with pa.SchedulerService(device=0, max_machines=8, max_tasks=64, max_jobs=4) as s:
+    with pa.SchedulerService(device=0, max_machines=8, max_tasks=64, max_jobs=4, reschedule_running=True) as s:
         warm = 0
         for burst in range(14):
             random_rpcs(s, rng, st, shapes, int(rng.integers(10, 80)))
@@ -277,3 +277,124 @@ def test_random_rpc_sequences_scheduled_on_the_gpu(seed):
                 res = s.task_placement(u)
                 assert res == "" or res in st.machines
         assert warm >= 5 and s.stats().rebuilds >= 2
+
+
+# ---- keep-running mode (the default): placed tasks hold their machine, a round only answers PLACE
+def _rounds_until_quiet(s, max_rounds=4):
+    """Schedule until a round reports nothing; every round's optimum is checked against the oracle's
+    on the network that round solved.  Returns all deltas."""
+    out = []
+    for _ in range(max_rounds):
+        g, _ = exported_graph(s)
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        deltas = s.Schedule()
+        st = s.stats()
+        if st.solve_ms > 0:
+            assert rc == 0 and tc == st.total_cost
+        if not deltas:
+            break
+        out += deltas
+    return out
+
+
+def test_running_tasks_keep_their_machines_through_churn():
+    """Default mode: a task that has been placed leaves the network and holds its machine.  After
+    5 % churn the rounds report only tasks that arrived, were pending, or whose machine went away, all
+    as PLACE; nobody else moves, and every round's optimum equals the oracle's on the network the
+    round solved (running tasks priced in as usage of their machines)."""
+    cfg, seed = 0, 4
+    cl = synth.make_cluster(cfg, seed)
+    with pa.SchedulerService(device=0) as s:
+        uids = feed_cluster(s, cl)
+        g, _ = exported_graph(s)
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        deltas = s.Schedule()
+        st = s.stats()
+        assert rc == 0 and tc == st.total_cost == oracle_cost(cl)  # nothing runs yet: the synthetic optimum
+        assert all(d.type == CT.PLACE for d in deltas)
+        assert st.tasks_running == len(deltas) == st.tasks_placed
+        deltas += _rounds_until_quiet(s)
+        nxt = int(uids.max()) + 1
+        restat = set()
+        for rnd in (1, 2):
+            before = {int(u): s.task_placement(int(u)) for u in uids}
+            cl, ch = synth.churn(cl, cfg, seed, rnd)
+            new_uids = apply_churn(s, cl, ch, uids, nxt)
+            nxt += ch.pods_replaced.shape[0]
+            restat |= set(int(m) for m in ch.machines_restat)
+            live = set(int(u) for u in new_uids)
+            arrived = live - set(int(u) for u in uids)
+            gone_machines = set(machine_uuid(int(m)) for m in np.nonzero(cl.machine_out)[0])
+            displaced = {u for u, res in before.items() if res in gone_machines and u in live}
+            pending_before = {u for u, res in before.items() if res == "" and u in live}
+            uids = new_uids
+            deltas = _rounds_until_quiet(s)
+            assert all(d.type == CT.PLACE for d in deltas)
+            moved = set(d.task_id for d in deltas)
+            assert len(moved) == len(deltas)
+            assert moved <= arrived | displaced | pending_before
+            assert len(moved & (arrived | displaced)) >= (len(arrived) + len(displaced)) // 2
+            for d in deltas:
+                assert d.resource_id not in gone_machines
+            for u in live - moved - arrived - displaced:  # everybody else is exactly where they were
+                assert s.task_placement(u) == before[u]
+            # no machine holds more than its slots, nor (where the statistics did not change under it) its capacity
+            load, cpu = collections.Counter(), collections.Counter()
+            shape_of = {int(u): int(cl.pod_shape[t]) for t, u in enumerate(uids)}
+            for u in live:
+                res = s.task_placement(u)
+                if res:
+                    assert res not in gone_machines
+                    m = machine_index(res)
+                    load[m] += 1
+                    cpu[m] += int(cl.req_cpu[shape_of[u]])
+            assert max(load.values()) <= cl.slots
+            for m, c in cpu.items():
+                if m not in restat:
+                    assert c + int(cl.used_cpu[m]) <= int(cl.cap_cpu[m]), m
+
+
+def test_filled_nodes_leave_the_extra_pod_pending():
+    """/root/reference/test/e2e/poseidon_integration.go:310-408: one filler pod per node asking for
+    70 % of that node's CPU, then a pod asking for 50 % of the largest node: it must stay pending."""
+    caps = [8000, 16000, 4000]
+    with pa.SchedulerService(device=0) as s:
+        for m, c in enumerate(caps):
+            assert s.NodeAdded(machine_uuid(m), c, 64 << 20) == NR.NODE_ADDED_OK
+        for i, c in enumerate(caps):
+            assert s.TaskSubmitted(1 + i, job_uuid(i), c * 7 // 10, 1 << 20) == TR.TASK_SUBMITTED_OK
+        placed = {}
+        for _ in range(4):  # fillers of different shapes may need more than one round
+            for d in s.Schedule():
+                assert d.type == CT.PLACE
+                placed[d.task_id] = machine_index(d.resource_id)
+        assert sorted(placed) == [1, 2, 3]
+        used = collections.Counter()
+        for u, m in placed.items():
+            used[m] += caps[u - 1] * 7 // 10
+        assert all(used[m] <= caps[m] for m in used)
+        assert s.TaskSubmitted(10, job_uuid(9), max(caps) // 2, 1 << 20) == TR.TASK_SUBMITTED_OK
+        for _ in range(3):
+            assert s.Schedule() == []
+        assert s.task_placement(10) == ""
+        # a filler goes away: the extra pod takes the node that has room for it now
+        big = [u for u, m in placed.items() if m == 1]
+        for u in big:
+            assert s.TaskRemoved(u) == TR.TASK_REMOVED_OK
+        deltas = s.Schedule()
+        assert [(d.task_id, d.type, machine_index(d.resource_id)) for d in deltas] == [(10, CT.PLACE, 1)]
+
+
+def test_two_classes_cannot_overcommit_a_machine_in_one_round():
+    with pa.SchedulerService(device=0) as s:
+        assert s.NodeAdded(machine_uuid(0), 10000, 64 << 20) == NR.NODE_ADDED_OK
+        assert s.TaskSubmitted(1, job_uuid(0), 6000, 1 << 20) == TR.TASK_SUBMITTED_OK
+        assert s.TaskSubmitted(2, job_uuid(0), 6000, 2 << 20) == TR.TASK_SUBMITTED_OK  # another class: same CPU, other memory
+        d1 = s.Schedule()
+        assert len(d1) == 1 and d1[0].type == CT.PLACE and s.stats().tasks_deferred == 1
+        assert s.Schedule() == [] and s.stats().tasks_running == 1
+        other = 2 if d1[0].task_id == 1 else 1
+        assert s.task_placement(other) == ""
+        assert s.TaskCompleted(d1[0].task_id) == TR.TASK_COMPLETED_OK
+        d2 = s.Schedule()
+        assert [(d.task_id, d.type) for d in d2] == [(other, CT.PLACE)]
