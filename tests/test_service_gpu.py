@@ -361,14 +361,18 @@ def test_filled_nodes_leave_the_extra_pod_pending():
     with pa.SchedulerService(device=0) as s:
         for m, c in enumerate(caps):
             assert s.NodeAdded(machine_uuid(m), c, 64 << 20) == NR.NODE_ADDED_OK
-        for i, c in enumerate(caps):
-            assert s.TaskSubmitted(1 + i, job_uuid(i), c * 7 // 10, 1 << 20) == TR.TASK_SUBMITTED_OK
+        from poseidon_amd.service import IN_SET
+        for m in range(len(caps)):
+            assert s.NodeLabels(machine_uuid(m), {"kubernetes.io/hostname": f"node-{m}"}) == NR.NODE_UPDATED_OK
+        for i, c in enumerate(caps):  # "one pod with affinity to each node that uses 70% of the node CPU" (:301)
+            assert s.TaskSubmitted(1 + i, job_uuid(i), c * 7 // 10, 1 << 20,
+                                   selectors=[(IN_SET, "kubernetes.io/hostname", [f"node-{i}"])]) == TR.TASK_SUBMITTED_OK
         placed = {}
-        for _ in range(4):  # fillers of different shapes may need more than one round
+        for _ in range(3):
             for d in s.Schedule():
                 assert d.type == CT.PLACE
                 placed[d.task_id] = machine_index(d.resource_id)
-        assert sorted(placed) == [1, 2, 3]
+        assert placed == {1: 0, 2: 1, 3: 2}
         used = collections.Counter()
         for u, m in placed.items():
             used[m] += caps[u - 1] * 7 // 10
