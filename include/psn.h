@@ -204,6 +204,16 @@ int psn_get_placements(psn_ctx *ctx, const psn_layout *layout, int32_t *task_to_
  * context's GPU, e.g. the send buffer of an all-gather; returns after the copy is done. */
 int psn_get_placements_device(psn_ctx *ctx, const psn_layout *layout, void *dst_device);
 
+/* psn_get_placements_device for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc): same result into the same kind of
+ * caller-owned device buffer, but the per-class unit lists the extraction kernel needs live in a
+ * fixed 4 MiB device array that every GPU the library runs on holds from the first psn_create
+ * on it until the process ends, and the call makes no device or host allocation of any kind.
+ * Limit: n_classes * n_tasks <= 1 048 576 (PSN_EINVAL beyond it, nothing launched).  All
+ * contexts of one GPU share that array: calls that overlap on one GPU race, the caller
+ * serialises them.  This entry point has no counterpart in the reference. */
+int psn_get_placements_device_noalloc(psn_ctx *ctx, const psn_layout *layout, void *dst_device);
+
 /* Placements of `count` solved contexts into one buffer, row i (int32, `stride` entries apart,
  * layouts[i].n_tasks of them written) for ctxs[i].  The contexts may live on different GPUs of
  * the node: every context runs its extraction on its own device and stream, then the rows are

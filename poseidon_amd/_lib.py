@@ -34,7 +34,7 @@ EXPORTS = [
     "psn_svc_node_added", "psn_svc_node_updated", "psn_svc_node_failed", "psn_svc_node_removed",
     "psn_svc_add_node_stats", "psn_svc_check", "psn_svc_schedule", "psn_svc_get_deltas", "psn_svc_get_stats",
     "psn_svc_task_submitted_sel", "psn_svc_node_labels", "psn_svc_export_mask", "psn_svc_network_size", "psn_svc_export_network", "psn_svc_task_placement", "psn_svc_solver",
-    "psn_gather_placements", "psn_debug_alloc_count",
+    "psn_gather_placements", "psn_debug_alloc_count", "psn_get_placements_device_noalloc",
 ]
 
 
@@ -99,6 +99,7 @@ def load_library():
     lib.psn_get_costs.argtypes = [vp, vp, vp]
     lib.psn_get_placements.argtypes = [vp, C.POINTER(Layout), vp]
     lib.psn_get_placements_device.argtypes = [vp, C.POINTER(Layout), vp]
+    lib.psn_get_placements_device_noalloc.argtypes = [vp, C.POINTER(Layout), vp]
     lib.psn_kernel_times.argtypes = [vp, vp, vp]
     lib.psn_placements_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     lib.psn_synth_cluster.argtypes = [i32, u64, C.POINTER(Layout), vp, vp, vp, vp, vp, vp, vp, vp]

@@ -11,6 +11,7 @@
 #include <utility>
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -102,6 +103,28 @@ hipError_t counted_host_malloc(void **p, size_t bytes) {
     return hipHostMalloc(p, bytes, hipHostMallocDefault);
 }
 constexpr int kFlagWords = 16;
+
+// ---- scratch of the entry point that allocates nothing (psn_get_placements_device_noalloc)
+// One array per GPU the library runs on, held until the process ends.  Host code never uses the
+// array's name as an address: the per-device address is looked up once per device when the first
+// context on that device is created, and that pointer is what kernels and copies are given.
+constexpr size_t kNoAllocInts = (size_t)1 << 20;  // classes x tasks the entry point can serve: 4 MiB per GPU
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) int scratch[kNoAllocInts];
+int *g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+// Device `device` must be current.
+hipError_t resolve_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    int *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = ptr;
+    return hipSuccess;
+}
 
 template <typename T>
 int dalloc(psn_ctx *c, T **p, size_t count) {
@@ -337,6 +360,7 @@ int psn_create(const psn_config *cfg, psn_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = counted_host_malloc((void **)&c->h_ctrl, sizeof(Ctrl));
     if (e == hipSuccess) e = counted_host_malloc((void **)&c->h_flag, kFlagWords * sizeof(unsigned));
+    if (e == hipSuccess) e = resolve_scratch(c->device);
     if (e != hipSuccess) { psn_destroy(c); return PSN_EDEVICE; }
     c->serial = g_ctx_serial.fetch_add(1) + 1;
     *out = c;
@@ -1305,6 +1329,22 @@ int psn_gather_placements(psn_ctx *const *ctxs, int32_t count, const psn_layout 
 }
 
 uint64_t psn_debug_alloc_count(void) { return g_alloc_calls.load(); }
+
+int psn_get_placements_device_noalloc(psn_ctx *c, const psn_layout *lay, void *dst_device) {
+    if (!c || !dst_device) return fail(c, PSN_EINVAL, "null argument");
+    int rc = check_place_layout(c, lay);
+    if (rc != PSN_OK) return rc;
+    if ((size_t)lay->n_classes * (size_t)lay->n_tasks > kNoAllocInts)
+        return fail(c, PSN_EINVAL, "classes x tasks exceeds the scratch of the no-allocation entry point (1048576 entries)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int *ptr = c->device < kMaxDevices ? g_scratch_ptr[c->device] : nullptr;
+    if (!ptr) return fail(c, PSN_ESTATE, "scratch address of this device was not resolved");
+    // the unit lists of the classes live in the per-device scratch while the kernel runs; nothing in it
+    // needs to start at zero (every entry that is read has been written by the same launch)
+    if ((rc = launch_placements(c, lay, static_cast<int *>(dst_device), ptr, lay->n_tasks)) != PSN_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return finish_placements(c);
+}
 
 int psn_placements_device_ptr(psn_ctx *c, void **dptr, int64_t *count) {
     if (!c || !dptr || !count) return fail(c, PSN_EINVAL, "null argument");
