@@ -191,10 +191,16 @@ int psn_solve_batch(psn_ctx *const *ctxs, int32_t count, uint32_t flags, int32_t
 
 /* Read back: flow on every residual arc (original minus residual capacity, >= 0 on
  * arcs carrying flow, <= 0 on their pairs), scaled prices (1-optimal for costs
- * multiplied by n+1), and task -> machine index (-1 = unscheduled) for psn-layout
+ * multiplied by the factor psn_price_scale reports), and task -> machine index (-1 = unscheduled) for psn-layout
  * networks.  Placements feed the SchedulingDelta list the caller returns
  * (/root/reference/pkg/firmament/scheduling_delta.proto:25-41). */
 int psn_get_flow(psn_ctx *ctx, int32_t *flow /* m2 */);
+/* The factor S the solver multiplies costs by: the prices psn_get_prices returns are 1-optimal
+ * for costs * S (cost[a] * S + price[tail] - price[head] >= -1 on every residual arc), and S
+ * exceeds the length of every simple cycle of the network, which makes such a flow optimal.  S is
+ * n + 1 at most; the library derives a smaller bound from a vertex cover of the network (a simple
+ * cycle is at most twice as long as a vertex cover is large), which saves refine phases. */
+int psn_price_scale(psn_ctx *ctx, int64_t *scale);
 int psn_get_residual(psn_ctx *ctx, int32_t *cap /* m2 */);
 int psn_get_prices(psn_ctx *ctx, int64_t *price /* n */);
 int psn_get_costs(psn_ctx *ctx, int32_t *cost /* m2 */, int32_t *cap_orig /* m2 */);

@@ -147,12 +147,15 @@ def cost_scaling(g, alpha: int = 12, flags: int = 0):
     return rc, tc.value, cap, price, st
 
 
-def check(g, cap_final, price_hint=None):
+def check(g, cap_final, price_hint=None, scale: int | None = None):
     """Certificate.  -> (rc, total_cost, potentials); rc 0 = feasible and optimal,
-    1 = conservation, 2 = bounds/structure, 3 = not optimal."""
+    1 = conservation, 2 = bounds/structure, 3 = not optimal.  price_hint: scaled prices to start
+    the checker's own potentials from (scaled by `scale`, default n + 1); only a starting point."""
     tc = C.c_int64(0)
     pot = np.zeros(g.n, np.int64)
     cap_final = np.ascontiguousarray(cap_final, dtype=np.int32)
+    if price_hint is not None and scale is not None and scale != g.n + 1:
+        price_hint = np.floor(np.asarray(price_hint, np.float64) / float(scale)).astype(np.int64) * (g.n + 1)
     hint = None if price_hint is None else _p(np.ascontiguousarray(price_hint, np.int64), np.int64)
     rc = lib().psn_oracle_check(C.c_int32(g.n), C.c_int64(_m2(g)), _p(g.row_off, np.int64),
                                 _p(g.head, np.int32), _p(g.cap, np.int32), _p(cap_final, np.int32),
@@ -161,10 +164,23 @@ def check(g, cap_final, price_hint=None):
     return rc, tc.value, pot
 
 
-def check_eps(g, cap_final, price, eps: int = 1) -> int:
-    """Number of residual arcs violating eps-optimality under scaled prices (-1: eps too big)."""
+def cycle_bound(g) -> int:
+    """Upper bound on the length of a simple cycle of g (vertex-cover argument)."""
+    lib().psn_oracle_cycle_bound.restype = C.c_int64
+    return int(lib().psn_oracle_cycle_bound(C.c_int32(g.n), _p(g.row_off, np.int64), _p(g.head, np.int32)))
+
+
+def check_eps(g, cap_final, price, eps: int = 1, scale: int | None = None) -> int:
+    """Number of residual arcs violating eps-optimality under prices scaled by `scale` (default
+    n + 1); -1 when eps is too large for that scale to imply optimality."""
     cap_final = np.ascontiguousarray(cap_final, dtype=np.int32)
     price = np.ascontiguousarray(price, dtype=np.int64)
+    if scale is not None:
+        lib().psn_oracle_check_eps_scaled.restype = C.c_int64
+        return int(lib().psn_oracle_check_eps_scaled(C.c_int32(g.n), C.c_int64(_m2(g)), _p(g.row_off, np.int64),
+                                                     _p(g.head, np.int32), _p(cap_final, np.int32),
+                                                     _p(g.cost, np.int32), _p(price, np.int64), C.c_int64(eps),
+                                                     C.c_int64(scale)))
     return int(lib().psn_oracle_check_eps(C.c_int32(g.n), C.c_int64(_m2(g)), _p(g.row_off, np.int64),
                                           _p(g.head, np.int32), _p(cap_final, np.int32),
                                           _p(g.cost, np.int32), _p(price, np.int64), C.c_int64(eps)))

@@ -602,6 +602,42 @@ int psn_oracle_check(i32 n, i64 m2, const i64 *row_off, const i32 *head, const i
     return rc;
 }
 
+/* Upper bound on the length of a simple cycle of the network, from a vertex cover: every arc of
+ * a cycle has an endpoint in the cover and a simple cycle passes a vertex once, so it has at most
+ * 2 * |cover| arcs (and at most n).  The cover is the complement of the independent set
+ * { v : every neighbour has a longer row than v, ties broken by id }; self-loops are ignored. */
+i64 psn_oracle_cycle_bound(i32 n, const i64 *row_off, const i32 *head) {
+    i64 cover = 0;
+    for (i32 v = 0; v < n; ++v) {
+        const i64 dv = row_off[v + 1] - row_off[v];
+        int out = 1;
+        for (i64 a = row_off[v]; a < row_off[v + 1] && out; ++a) {
+            const i32 u = head[a];
+            if (u == v) continue;
+            const i64 du = row_off[u + 1] - row_off[u];
+            if (!(du > dv || (du == dv && u > v))) out = 0;
+        }
+        cover += !out;
+    }
+    return 2 * cover < (i64)n ? 2 * cover : (i64)n;
+}
+
+/* Scaled-price certificate for an arbitrary cost multiplier `scale`: every residual arc has
+ * cost*scale + price[u] - price[v] >= -eps, and eps * (longest simple cycle) < scale, which for
+ * integer costs implies optimality (a residual cycle of cost <= -1 would have scaled cost
+ * <= -scale, but its reduced costs sum to >= -eps * length).  Returns the number of violating
+ * arcs, -1 when eps is too large for the scale. */
+i64 psn_oracle_check_eps_scaled(i32 n, i64 m2, const i64 *row_off, const i32 *head, const i32 *cap_final,
+                                const i32 *cost, const i64 *price, i64 eps, i64 scale) {
+    i64 bad = 0;
+    (void)m2;
+    if (eps * psn_oracle_cycle_bound(n, row_off, head) >= scale) return -1;
+    for (i32 u = 0; u < n; ++u)
+        for (i64 a = row_off[u]; a < row_off[u + 1]; ++a)
+            if (cap_final[a] > 0 && (i64)cost[a] * scale + price[u] - price[head[a]] < -eps) ++bad;
+    return bad;
+}
+
 /* Scaled-price certificate: every residual arc has cost*(n+1)+price[u]-price[v] >= -eps
  * with eps*n < n+1, which for integer costs implies optimality (Goldberg-Tarjan 1990,
  * Thm 3.3 restated for costs multiplied by n+1).  Returns the number of violating arcs. */

@@ -34,7 +34,7 @@ EXPORTS = [
     "psn_svc_node_added", "psn_svc_node_updated", "psn_svc_node_failed", "psn_svc_node_removed",
     "psn_svc_add_node_stats", "psn_svc_check", "psn_svc_schedule", "psn_svc_get_deltas", "psn_svc_get_stats",
     "psn_svc_task_submitted_sel", "psn_svc_node_labels", "psn_svc_export_mask", "psn_svc_network_size", "psn_svc_export_network", "psn_svc_task_placement", "psn_svc_solver",
-    "psn_gather_placements", "psn_debug_alloc_count", "psn_get_placements_device_noalloc",
+    "psn_gather_placements", "psn_debug_alloc_count", "psn_get_placements_device_noalloc", "psn_price_scale",
 ]
 
 
@@ -97,6 +97,7 @@ def load_library():
     lib.psn_get_residual.argtypes = [vp, vp]
     lib.psn_get_prices.argtypes = [vp, vp]
     lib.psn_get_costs.argtypes = [vp, vp, vp]
+    lib.psn_price_scale.argtypes = [vp, C.POINTER(i64)]
     lib.psn_get_placements.argtypes = [vp, C.POINTER(Layout), vp]
     lib.psn_get_placements_device.argtypes = [vp, C.POINTER(Layout), vp]
     lib.psn_get_placements_device_noalloc.argtypes = [vp, C.POINTER(Layout), vp]

@@ -71,6 +71,9 @@ struct psn_ctx {
     unsigned *h_flag = nullptr;  // pinned, kFlagWords words
     // identity for caches that outlive a call: never reused, bumped on every upload
     unsigned long long serial = 0, upload_gen = 0;
+    // vertex cover behind the cost scale: flags per vertex, size found, size the current scale allows for
+    unsigned char *d_in_cover = nullptr;
+    long long cover_size = 0, cover_cap = 0;
     struct GroupCache *gcache = nullptr;  // lockstep group led by this context, kept between batch calls
 };
 
@@ -164,6 +167,7 @@ void free_graph_buffers(psn_ctx *c) {
     ++c->upload_gen;
     c->uploaded = c->solved = false;
     c->d_place = c->d_slot_machine = nullptr;
+    c->d_in_cover = nullptr; c->cover_size = c->cover_cap = 0;
     c->d_allow = nullptr; c->allow_words = c->allow_classes = 0; c->allow_on = false;
     c->place_count = c->slot_stride = c->slot_classes = 0;
 }
@@ -261,6 +265,30 @@ __global__ void k_check_arcs(int n, unsigned m2, const int *head, const int *cap
     }
 }
 
+// Vertex cover for the cost scale.  A flow that is 1-optimal for costs multiplied by S is optimal
+// as soon as S exceeds the length of every simple residual cycle: such a cycle of (unscaled) cost
+// <= -1 would have scaled cost <= -S, while its reduced costs sum to >= -length.  A simple cycle
+// passes every vertex once and each of its arcs has an endpoint in any vertex cover, so its length
+// is at most twice the size of the cover.  The cover taken here is the complement of the
+// independent set { v : every neighbour has a longer row than v (ties: a larger id) }; capacities
+// play no part, so the bound holds whatever the cost model or an update does to them.  In a
+// scheduling network the tasks and the machines stay out of the cover: S drops from n + 1 to
+// about 2 * (classes + jobs), which is one refine phase less.
+__global__ void k_cover_mark(const unsigned *row, int n, unsigned m2, const int *head, const int *tail, unsigned char *in_cover) {
+    for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < m2; a += gridDim.x * kBlock) {
+        const int t = tail[a], h = head[a];
+        if (h == t || (unsigned)h >= (unsigned)n) continue;  // placeholder self-loop / rejected elsewhere
+        const unsigned dt = row[t + 1] - row[t], dh = row[h + 1] - row[h];
+        if (!(dh > dt || (dh == dt && h > t))) in_cover[t] = 1;  // a neighbour that is not "larger": t cannot stay out
+    }
+}
+__global__ void k_cover_count(const unsigned char *in_cover, int n, unsigned *out) {
+    unsigned c = 0;
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) c += in_cover[v];
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0 && c) __hip_atomic_fetch_add(out, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Cost statistics of the arcs that can carry flow: out[0] = max |cost|, out[1] = number with a
 // negative cost, out[2 + b] = number with 2^(b-1) < cost <= 2^b (b = 0 holds costs 0 and 1).
 __global__ void k_cost_stats(DevGraph g, i64 *out) {
@@ -311,6 +339,29 @@ constexpr int kSupplySumSlot = 38;  // d_scalar: [0] total cost, [1] max violati
 #ifdef PSN_STAMPS
 constexpr size_t kStampWords = (size_t)65536 + (size_t)8 * 64 * 4096 * 2 + (size_t)8 * 64 * 2;
 #endif
+
+// Marks and counts the vertex cover of the resident network on the context's stream; the count is
+// on its way to h_flag[2] when this returns (d_scalar slot kCoverSlot is the device counter).
+constexpr int kCoverSlot = 37;
+int launch_cover(psn_ctx *c) {
+    const DevGraph &g = c->g;
+    unsigned *d_cnt = reinterpret_cast<unsigned *>(c->d_scalar + kCoverSlot);
+    HIPCHK(c, hipMemsetAsync(c->d_in_cover, 0, (size_t)g.n, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, sizeof(unsigned), c->stream));
+    if (g.m2) hipLaunchKernelGGL(k_cover_mark, dim3(kGrid), dim3(kBlock), 0, c->stream, g.row, g.n, g.m2, g.head, g.tail, c->d_in_cover);
+    hipLaunchKernelGGL(k_cover_count, dim3(std::max(1, std::min(256, (g.n + kBlock - 1) / kBlock))), dim3(kBlock), 0, c->stream, c->d_in_cover, g.n, d_cnt);
+    HIPCHK(c, hipMemcpyAsync(c->h_flag + 2, d_cnt, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    return PSN_OK;
+}
+// The cost scale that goes with a cover of `cover` vertices, with room for the cover to grow a
+// little (tasks and jobs that arrive later) before the scale has to change.
+void scale_for_cover(psn_ctx *c, long long cover) {
+    c->cover_size = cover;
+    c->cover_cap = cover + std::max<long long>(64, cover / 8);
+    i64 len = std::min<i64>((i64)c->g.n, 2 * (i64)c->cover_cap);  // no simple cycle is longer
+    if (std::getenv("PSN_SCALE_N")) len = c->g.n;                 // diagnostics: the textbook scale n + 1
+    c->g.scale = len + 1;
+}
 
 int ceil_log2(i64 x) {
     int s = 0;
@@ -455,7 +506,7 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     A(d_row, n + 1) A(d_head, m2) A(c->d_cost, m2) A(d_rev, m2) A(d_tail, m2) A(c->d_ocap, m2) A(d_cls, n) A(d_hub_of, n) A(d_hub_vertex, kMaxHubs)
     A(d_hub_row0, kMaxHubs) A(d_hub_seg0, kMaxHubs) A(d_seg1_of, n) A(g.seg_scan, n_hub_segs) A(g.seg_add[0], n_hub_segs) A(g.seg_add[1], n_hub_segs)
     A(g.cap, m2) A(g.rcap, m2) A(g.price, n) A(g.excess, n) A(g.cand, n) A(g.dist, n)
-    A(c->d_supply, n) A(c->d_scalar, kScalarSlots)
+    A(c->d_supply, n) A(c->d_scalar, kScalarSlots) A(c->d_in_cover, n)
     for (int i = 0; i < 2; ++i) { A(g.list_low[i], n) A(g.list_seg[i], (size_t)n + high_items) }
     for (int i = 0; i < 3; ++i) { A(g.fr_low[i], n) A(g.fr_seg[i], (size_t)n + high_items) }
     c->tally_slots = kGrid * (kBlock / 64);
@@ -495,6 +546,7 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
         hipLaunchKernelGGL(k_check_arcs, dim3(kGrid), dim3(kBlock), 0, s, (int)n, (unsigned)m2, d_head, g.cap, c->d_cost, d_rev, d_tail, d_chk);
     }
     HIPCHK(c, hipMemcpyAsync(h_chk, d_chk, sizeof(h_chk), hipMemcpyDeviceToHost, s));
+    if ((rc = launch_cover(c)) != PSN_OK) { free_graph_buffers(c); return rc; }
     HIPCHK(c, hipStreamSynchronize(s));  // host staging vectors die at return
     if (h_chk[0] != ~0ull) {  // name what is wrong with the first unsound arc
         free_graph_buffers(c);
@@ -514,6 +566,7 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
         const long double bound = 8.0L * (long double)n * (long double)(h_chk[1] + 1) * (long double)(n + 1);
         if (bound > 4.0e18L) { free_graph_buffers(c); return fail(c, PSN_EOVERFLOW, "n^2 * max|cost| too large for int64 prices"); }
     }
+    scale_for_cover(c, (long long)c->h_flag[2]);
     const double tu4 = now_up();
     if ((rc = build_graph(c)) != PSN_OK) { free_graph_buffers(c); return rc; }
     if (dbg_up) fprintf(stderr, "psn_upload_csr: checks %.1f free %.1f classify+alloc %.1f copies %.1f graph capture %.1f ms\n", tu1 - tu0, tu2 - tu1, tu3 - tu2, tu4 - tu3, now_up() - tu4);
@@ -660,12 +713,24 @@ int psn_patch_arcs(psn_ctx *c, int64_t count, const int64_t *arc_index, const in
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(c->h_flag, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && launch_cover(c) != PSN_OK) return PSN_EDEVICE;  // rewired arcs may have grown the vertex cover
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_patch_arcs", e);
     bad = c->h_flag[0];
     if (bad) {
         c->uploaded = c->solved = false;  // the device network is inconsistent: upload again
         return fail(c, PSN_EINVAL, "patched arcs do not pair up; the network must be uploaded again");
+    }
+    c->cover_size = (long long)c->h_flag[2];
+    if (c->cover_size > c->cover_cap) {
+        // longer residual cycles are possible now: a larger cost scale, under which the kept prices mean
+        // nothing, so the next solve starts cold; the replay graph carries the scale and is captured anew
+        scale_for_cover(c, c->cover_size);
+        c->solved = false;
+        ++c->upload_gen;
+        drop_group_cache(c);
+        const int rcg = build_graph(c);
+        if (rcg != PSN_OK) return rcg;
     }
     return PSN_OK;
 }
@@ -787,6 +852,7 @@ static int solve_start(psn_ctx *c, hipStream_t s, bool warm, const i64 *h_scalar
         shift0 = ceil_log2(c0 * g.scale) - init.alpha_log2;
     } else {
         // the kept pseudoflow is v-optimal for v = largest violation: resume one step below it
+        if (const char *ev = std::getenv("PSN_WARM_ALPHA_LOG2")) init.alpha_log2 = std::max(1, std::min(12, atoi(ev)));
         shift0 = h_scalar[1] > 1 ? ceil_log2(h_scalar[1]) - init.alpha_log2 : 0;
     }
     if (shift0 < 0) shift0 = 0;
@@ -1182,6 +1248,13 @@ int psn_get_prices(psn_ctx *c, int64_t *price) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(price, c->g.price, (size_t)c->n * sizeof(i64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSN_OK;
+}
+
+int psn_price_scale(psn_ctx *c, int64_t *scale) {
+    if (!c || !scale) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    *scale = c->g.scale;
     return PSN_OK;
 }
 

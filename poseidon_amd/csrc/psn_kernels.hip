@@ -1310,7 +1310,11 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
             if (ct->eps_shift == 0) {
                 ct->done = 1;
             } else {
-                ct->eps_shift = ct->eps_shift > ct->alpha_log2 ? ct->eps_shift - ct->alpha_log2 : 0;
+                // next phase: epsilon / alpha; a last step that would be less than half a phase is
+                // folded into this one (a phase costs about the same whatever its step)
+                int nxt = ct->eps_shift > ct->alpha_log2 ? ct->eps_shift - ct->alpha_log2 : 0;
+                if (2 * nxt <= ct->alpha_log2) nxt = 0;
+                ct->eps_shift = nxt;
                 ct->eps = (i64)1 << ct->eps_shift;
                 ct->need_sat = 1;
             }

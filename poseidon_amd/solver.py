@@ -139,6 +139,12 @@ class Solver:
         self._chk(self._lib.psn_get_prices(self._ctx, _vp(out)))
         return out
 
+    def price_scale(self) -> int:
+        """The factor costs are multiplied by: prices() are 1-optimal for cost * price_scale()."""
+        v = C.c_int64(0)
+        self._chk(self._lib.psn_price_scale(self._ctx, C.byref(v)))
+        return int(v.value)
+
     def costs(self):
         cost = np.empty(self.m2, np.int32)
         cap = np.empty(self.m2, np.int32)

@@ -51,8 +51,8 @@ def test_batch_across_two_lockstep_groups_matches_oracle():
     places = []
     for s, og, r, cl in zip(solvers, graphs, res, clusters):
         resid, price = s.residual(), s.prices()
-        assert capi.check(og, resid, price)[:2] == (0, r.total_cost)
-        assert capi.check_eps(og, resid, price, 1) == 0
+        assert capi.check(og, resid, price, scale=s.price_scale())[:2] == (0, r.total_cost)
+        assert capi.check_eps(og, resid, price, 1, scale=s.price_scale()) == 0
         p = s.placements()
         P = cl.layout.n_tasks
         assert int((p >= 0).sum()) == int((og.cap - resid)[og.fwd_pos[:P]].sum())  # routed tasks = flow on task -> class arcs

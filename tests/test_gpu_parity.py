@@ -48,10 +48,10 @@ def solve_and_certify(s, g):
     r = s.solve()
     resid = s.residual()
     price = s.prices()
-    crc, ctc, _ = capi.check(g, resid, price)
+    crc, ctc, _ = capi.check(g, resid, price, scale=s.price_scale())
     assert crc == 0, f"certificate failed with code {crc}"
     assert ctc == r.total_cost
-    assert capi.check_eps(g, resid, price, 1) == 0
+    assert capi.check_eps(g, resid, price, 1, scale=s.price_scale()) == 0
     flow = s.flow()
     assert np.array_equal(flow, g.cap - resid)
     return r
@@ -217,7 +217,7 @@ def test_synthetic_clusters_vs_golden_and_oracle(solver, cfg, seed):
     gold = _gold(cfg, seed)
     assert r.total_cost == gold["optimal_cost"]
     resid, price = solver.residual(), solver.prices()
-    assert capi.check(og, resid, price)[:2] == (0, r.total_cost)
+    assert capi.check(og, resid, price, scale=solver.price_scale())[:2] == (0, r.total_cost)
     # K5: every placed task sits on a machine that its class can use, within slot capacity
     place = solver.placements()
     N, K = cl.layout.n_machines, cl.layout.k_slots
@@ -247,6 +247,7 @@ def test_full_size_network_certificate():
         s.eval_costs(cl, net)
         r = s.solve()
         resid, price = s.residual(), s.prices()
+        pscale = s.price_scale()
         cost, ocap = s.costs()
         place = s.placements()
         # idempotence: a second cold solve gives the same cost
@@ -255,8 +256,8 @@ def test_full_size_network_certificate():
     assert r.total_cost == _gold(2, 1)["optimal_cost"] == r2.total_cost
     og = synth.build_graph(synth.make_cluster(2, 1))
     assert np.array_equal(cost, og.cost) and np.array_equal(ocap, og.cap)
-    assert capi.check(og, resid, price)[:2] == (0, r.total_cost)
-    assert capi.check_eps(og, resid, price, 1) == 0
+    assert capi.check(og, resid, price, scale=pscale)[:2] == (0, r.total_cost)
+    assert capi.check_eps(og, resid, price, 1, scale=pscale) == 0
     routed = int((og.cap - resid)[og.fwd_pos[:100000]].sum())  # flow on task -> class arcs
     assert int((place >= 0).sum()) == routed
     assert np.bincount(place[place >= 0], minlength=10000).max() <= cl.slots
@@ -291,7 +292,7 @@ def test_warm_start_after_capacity_change(solver):
     og.cap[arcs] = 0
     rc, tc, _, _, _ = capi.cost_scaling(og)
     assert rc == 0 and rw.total_cost == tc
-    assert capi.check(og, solver.residual(), solver.prices())[:2] == (0, tc)
+    assert capi.check(og, solver.residual(), solver.prices(), scale=solver.price_scale())[:2] == (0, tc)
 
 
 def test_batch_of_independent_networks_matches_oracle():
@@ -355,14 +356,14 @@ def test_lockstep_group_of_unlike_networks(monkeypatch):
         res = batch.solve_batch(solvers, workers=2)
         assert [r.total_cost for r in res] == want, cap
         for s, g, r in zip(solvers, graphs, res):
-            assert capi.check(g, s.residual(), s.prices())[:2] == (0, r.total_cost)
-            assert capi.check_eps(g, s.residual(), s.prices(), 1) == 0
+            assert capi.check(g, s.residual(), s.prices(), scale=s.price_scale())[:2] == (0, r.total_cost)
+            assert capi.check_eps(g, s.residual(), s.prices(), 1, scale=s.price_scale()) == 0
     # one infeasible member: the call reports it, the other members are solved all the same
     with pytest.raises(_lib.PsnError) as ei:
         batch.solve_batch(solvers[:3] + [sb] + solvers[3:], workers=1)
     assert ei.value.code == _lib.PSN_EINFEASIBLE
     for s, g, w in zip(solvers, graphs, want):
-        assert capi.check(g, s.residual(), s.prices())[:2] == (0, w)
+        assert capi.check(g, s.residual(), s.prices(), scale=s.price_scale())[:2] == (0, w)
     # warm group solve after capacity changes on two members
     for i in (0, 4):
         g = graphs[i]

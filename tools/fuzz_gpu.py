@@ -107,7 +107,7 @@ def groups(budget, rng):
                 if want[i] is None:
                     count["infeasible"] += 1
                     continue
-                crc, ctc, _ = capi.check(g, pool[i].residual(), pool[i].prices())
+                crc, ctc, _ = capi.check(g, pool[i].residual(), pool[i].prices(), scale=pool[i].price_scale())
                 assert crc == 0 and ctc == want[i], (i, crc, ctc, want[i])
                 if res is not None:
                     assert res[i].total_cost == want[i]
@@ -142,7 +142,7 @@ def main():
                     assert rc != 0 and e.code == -4, (kind, rc, e)
                     continue
                 assert rc == 0 and r.total_cost == want, (kind, g.n, rc, want, r.total_cost)
-                crc, ctc, _ = capi.check(g, sv.residual(), sv.prices())
+                crc, ctc, _ = capi.check(g, sv.residual(), sv.prices(), scale=sv.price_scale())
                 assert crc == 0 and ctc == want, (kind, crc)
             count[kind] += 1
             if rc == 0 and rng.random() < 0.5:  # perturb capacities, warm start
