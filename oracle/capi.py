@@ -88,13 +88,14 @@ def ssp(g):
     return rc, tc.value, cap, pot
 
 
-CS_EPS_PERCENTILE, CS_PRICE_REFINE = 1, 2
+CS_EPS_PERCENTILE, CS_PRICE_REFINE, CS_COVER_SCALE = 1, 2, 4
 # The timed CPU baseline: the plain textbook variant (the one the parity tests use as the oracle)
 # and the tuned one (the GPU solver's first epsilon and alpha = 16, price refinement before each
 # later phase).  Arc fixing and push look-ahead are not implemented.
 BASELINE_VARIANTS = {
     "plain (eps from max cost, alpha 12)": {},
     "tuned (eps from 90th-percentile cost, alpha 16, price refinement)": {"alpha": 16, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE},
+    "tuned + cost scale from the cycle-length bound (as the GPU solver)": {"alpha": 16, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE | CS_COVER_SCALE},
 }
 
 

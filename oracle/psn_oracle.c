@@ -451,6 +451,8 @@ static int cs_price_refine(cs_ctx *c, i64 eps) {
 
 #define ORC_CS_EPS_PERCENTILE 1 /* first epsilon from the 90th-percentile cost (valid when no usable arc has a negative cost) */
 #define ORC_CS_PRICE_REFINE 2   /* try price refinement before every phase but the first */
+#define ORC_CS_COVER_SCALE 4    /* multiply costs by (cycle-length bound + 1) instead of n + 1 */
+i64 psn_oracle_cycle_bound(i32 n, const i64 *row_off, const i32 *head);
 
 /* cap[] in: original residual capacities; out: final residual capacities.
  * price_out (may be NULL): scaled prices, 1-optimal w.r.t. cost*(n+1).
@@ -488,6 +490,7 @@ int psn_oracle_cost_scaling_ex(i32 n, i64 m2, const i64 *row_off, const i32 *hea
     if (!cap0 || !c.price || !c.excess || !c.cur || !c.q || !c.inq || !c.settled || !c.bnext ||
         !c.bprev || !c.dist || !c.bucket) { rc = ORC_ENOMEM; goto out; }
     if (alpha < 2) alpha = 12;
+    if (flags & ORC_CS_COVER_SCALE) c.S = psn_oracle_cycle_bound(n, row_off, head) + 1;
     memcpy(cap0, cap, sizeof(i32) * (size_t)m2);
     memcpy(c.excess, supply, sizeof(i64) * n);
     {

@@ -54,7 +54,8 @@ struct psn_ctx {
     hipGraphExec_t gexec = nullptr;
     int rounds = 8;
     int launches_per_replay = 0;
-    Ctrl *h_ctrl = nullptr;  // pinned
+    Ctrl *h_ctrl = nullptr;  // pinned, two slots: replays are kept two deep in the stream and read back alternately
+    hipEvent_t ev_rep[2] = {nullptr, nullptr};
     // per-kernel-class timing (PSN_CFG_KTIME, eager launches only): event pairs per launch
     std::vector<hipEvent_t> kt_ev;
     std::vector<int> kt_cls;
@@ -409,7 +410,9 @@ int psn_create(const psn_config *cfg, psn_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = counted_host_malloc((void **)&c->h_ctrl, sizeof(Ctrl));
+    if (e == hipSuccess) e = counted_host_malloc((void **)&c->h_ctrl, 2 * sizeof(Ctrl));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_rep[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_rep[1], hipEventDisableTiming);
     if (e == hipSuccess) e = counted_host_malloc((void **)&c->h_flag, kFlagWords * sizeof(unsigned));
     if (e == hipSuccess) e = resolve_scratch(c->device);
     if (e != hipSuccess) { psn_destroy(c); return PSN_EDEVICE; }
@@ -427,6 +430,7 @@ void psn_destroy(psn_ctx *c) {
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->h_ctrl) (void)hipHostFree(c->h_ctrl);
+    for (int i = 0; i < 2; ++i) if (c->ev_rep[i]) (void)hipEventDestroy(c->ev_rep[i]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -919,39 +923,55 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     const bool dbg_phases = std::getenv("PSN_DEBUG_SOLVE") != nullptr;
     std::string phase_log;
     int last_shift = -1; long long phase_replays = 0;
-    for (;;) {
+    // Graph replays are kept two deep in the stream: while the host looks at the control block replay i
+    // left behind, replay i + 1 is already running, so the device never waits for the host between
+    // replays.  A replay issued after the solve is over finds every stage switched off.
+    const int depth = c->gexec ? 2 : 1;
+    long long issued = 0, checked = 0;
+    auto issue = [&]() -> int {
+        const int slot = (int)(issued & 1);
         if (c->gexec) {
             HIPCHK(c, hipGraphLaunch(c->gexec, s));
         } else {
             enqueue_replay(c, s);
             HIPCHK(c, hipGetLastError());
         }
-        ++replays;
-        HIPCHK(c, hipMemcpyAsync(c->h_ctrl, g.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        for (size_t i = 0; i + 1 < c->kt_used; i += 2) {  // event pairs of this replay
-            float ems = 0.f;
-            const int cls = c->kt_cls[i];
-            if (cls >= 0 && hipEventElapsedTime(&ems, c->kt_ev[i], c->kt_ev[i + 1]) == hipSuccess) {
-                c->kt_ms[cls] += ems;
-                c->kt_calls[cls] += 1;
+        HIPCHK(c, hipMemcpyAsync(&c->h_ctrl[slot], g.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(c->ev_rep[slot], s));
+        ++issued;
+        return PSN_OK;
+    };
+    for (int i = 0; i < depth; ++i) if ((rc = issue()) != PSN_OK) return rc;
+    for (;;) {
+        const Ctrl &h = c->h_ctrl[checked & 1];
+        HIPCHK(c, hipEventSynchronize(c->ev_rep[checked & 1]));
+        ++checked;
+        if (depth == 1) {
+            for (size_t i = 0; i + 1 < c->kt_used; i += 2) {  // event pairs of this replay
+                float ems = 0.f;
+                const int cls = c->kt_cls[i];
+                if (cls >= 0 && hipEventElapsedTime(&ems, c->kt_ev[i], c->kt_ev[i + 1]) == hipSuccess) {
+                    c->kt_ms[cls] += ems;
+                    c->kt_calls[cls] += 1;
+                }
             }
+            c->kt_used = 0;
         }
-        c->kt_used = 0;
         if (dbg_phases) {
-            if (c->h_ctrl->eps_shift != last_shift && last_shift >= 0) { phase_log += " " + std::to_string(last_shift) + ":" + std::to_string(phase_replays + 1); phase_replays = 0; }
+            if (h.eps_shift != last_shift && last_shift >= 0) { phase_log += " " + std::to_string(last_shift) + ":" + std::to_string(phase_replays + 1); phase_replays = 0; }
             else ++phase_replays;
-            last_shift = c->h_ctrl->eps_shift;
+            last_shift = h.eps_shift;
         }
-        if (c->h_ctrl->error) { status = c->h_ctrl->error == PSN_EINFEASIBLE_DEV ? PSN_EINFEASIBLE : PSN_EDEVICE; break; }
-        if (c->h_ctrl->done) break;
+        if (h.error) { status = h.error == PSN_EINFEASIBLE_DEV ? PSN_EINFEASIBLE : PSN_EDEVICE; break; }
+        if (h.done) break;
         {   // the rounds of this replay emptied the work list at epsilon 1: solved (what the next k_begin would find)
-            const Ctrl &h = *c->h_ctrl;
             const unsigned *lc = h.list_cnt[c->rounds & 1];
             if (h.rounds_on && lc[kClsLow] + lc[kClsSeg] == 0 && h.eps_shift == 0) break;
         }
-        if (replays >= max_replays) { status = PSN_ELIMIT; break; }
+        if (checked >= max_replays) { status = PSN_ELIMIT; break; }
+        if ((rc = issue()) != PSN_OK) return rc;
     }
+    replays = issued;
     unsigned long long h_tally[kTallyN];
     i64 h_cost = 0;
     if ((rc = solve_finish(c, s, &h_cost, h_tally)) != PSN_OK) return rc;
@@ -1066,7 +1086,7 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
         gc->key = key;
         GCHK(counted_malloc((void **)&gc->d_graphs, G * sizeof(DevGraph)));
         GCHK(counted_malloc((void **)&gc->d_status, 2 * G * sizeof(int)));
-        GCHK(counted_host_malloc((void **)&gc->h_status, 2 * G * sizeof(int)));
+        GCHK(counted_host_malloc((void **)&gc->h_status, 2 * 2 * G * sizeof(int)));  // two read-back slots
         std::vector<DevGraph> h_graphs(G);
         for (size_t i = 0; i < G; ++i) h_graphs[i] = m[i]->g;
         GCHK(hipMemcpyAsync(gc->d_graphs, h_graphs.data(), G * sizeof(DevGraph), hipMemcpyHostToDevice, s));
@@ -1092,21 +1112,34 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
         GCHK(hipGraphInstantiate(&gc->gexec, gc->graph, nullptr, nullptr, 0));
     }
     t_c = now();
+    // replays are kept two deep in the stream (see psn_solve); status words are read back alternately
     int *h_status = gc->h_status;
     const long long max_replays = 200000;
+    long long issued = 0, checked = 0;
+    auto issue = [&]() -> hipError_t {
+        const int slot = (int)(issued & 1);
+        hipError_t e = hipGraphLaunch(gc->gexec, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(gc->h_status + (size_t)slot * 2 * G, gc->d_status, 2 * G * sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipEventRecord(lead->ev_rep[slot], s);
+        ++issued;
+        return e;
+    };
+    GCHK(issue());
+    GCHK(issue());
     for (;;) {
-        GCHK(hipGraphLaunch(gc->gexec, s));
-        ++replays;
-        GCHK(hipMemcpyAsync(h_status, gc->d_status, 2 * G * sizeof(int), hipMemcpyDeviceToHost, s));
-        GCHK(hipStreamSynchronize(s));
+        h_status = gc->h_status + (size_t)(checked & 1) * 2 * G;
+        GCHK(hipEventSynchronize(lead->ev_rep[checked & 1]));
+        ++checked;
         bool all = true;
         for (size_t i = 0; i < G; ++i) all = all && (h_status[2 * i] || h_status[2 * i + 1]);
         if (all) break;
-        if (replays >= max_replays) {
+        if (checked >= max_replays) {
             for (size_t i = 0; i < G; ++i) if (!h_status[2 * i] && !h_status[2 * i + 1]) status[i] = PSN_ELIMIT;
             break;
         }
+        GCHK(issue());
     }
+    replays = issued;
     t_d = now();
     for (size_t i = 0; i < G; ++i) {
         if (h_status[2 * i + 1]) status[i] = h_status[2 * i + 1] == PSN_EINFEASIBLE_DEV ? PSN_EINFEASIBLE : PSN_EDEVICE;
