@@ -128,6 +128,11 @@ int psn_eval_costs(psn_ctx *ctx, const psn_layout *layout, const int64_t *cap_cp
  * (vertex, new supply).  With PSN_WARM_START the next solve repairs the kept flow. */
 int psn_update_caps(psn_ctx *ctx, int64_t count, const int64_t *arc_index, const int32_t *new_cap);
 int psn_update_supplies(psn_ctx *ctx, int64_t count, const int32_t *vertex, const int64_t *new_supply);
+/* New costs of residual arcs (arc index, cost; the paired arc gets the negated cost).  Flow and
+ * prices are kept: with PSN_WARM_START the next solve repairs the optimality conditions the
+ * change broke.  With psn_update_caps this is what a DIMACS change record amounts to
+ * (include/psn_builder.h). */
+int psn_update_costs(psn_ctx *ctx, int64_t count, const int64_t *arc_index, const int32_t *new_cost);
 
 /* Label selectors as an admission mask: bit (m & 31) of word mask[e * ((N+31)/32) + m/32]
  * says whether tasks of class e may run on machine m.  Once set, psn_eval_costs and

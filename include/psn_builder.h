@@ -65,6 +65,21 @@ int psn_dimacs_size(const char *path, int32_t *n, int64_t *m);
 int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32_t *head, int32_t *cap,
                     int32_t *cost, int64_t *supply, int64_t *base_cost);
 
+/* Change records: a second file that edits a problem already read, so that the resident network
+ * can be edited in place and the solve warm-started: a later scheduling round described as changes
+ * to the previous one (for the same CPU solvers, /root/reference/LICENSE:18-26).  Lines:
+ *   x <tail> <head> 0 <cap> <cost> [<k>]   new capacity and cost of the k-th (default first) arc
+ *                                          tail -> head, counting parallel arcs in file order
+ *   n <vertex> <supply>                    new supply
+ * Arcs and vertices are neither added nor removed (capacity 0 takes an arc out); any other
+ * record is PSN_EINVAL.  psn_dimacs_changes_size counts the records, psn_dimacs_read_changes
+ * resolves them against the arc list psn_dimacs_read produced: arc[i] indexes that list.  Apply
+ * with psn_update_caps / psn_update_costs (arc positions from psn_csr_from_arcs' fwd_pos) and
+ * psn_update_supplies. */
+int psn_dimacs_changes_size(const char *path, int64_t *n_arc_changes, int64_t *n_supply_changes);
+int psn_dimacs_read_changes(const char *path, int32_t n, int64_t m, const int32_t *tail, const int32_t *head,
+                            int64_t *arc, int32_t *new_cap, int32_t *new_cost, int32_t *vertex, int64_t *new_supply);
+
 /* FNV-1a-64 over a byte range, chained through h (start with 0xCBF29CE484222325). */
 uint64_t psn_fnv1a64(const void *data, int64_t nbytes, uint64_t h);
 

@@ -34,7 +34,8 @@ EXPORTS = [
     "psn_svc_node_added", "psn_svc_node_updated", "psn_svc_node_failed", "psn_svc_node_removed",
     "psn_svc_add_node_stats", "psn_svc_check", "psn_svc_schedule", "psn_svc_get_deltas", "psn_svc_get_stats",
     "psn_svc_task_submitted_sel", "psn_svc_node_labels", "psn_svc_export_mask", "psn_svc_network_size", "psn_svc_export_network", "psn_svc_task_placement", "psn_svc_solver",
-    "psn_gather_placements", "psn_debug_alloc_count", "psn_get_placements_device_noalloc", "psn_price_scale",
+    "psn_gather_placements", "psn_debug_alloc_count", "psn_get_placements_device_noalloc", "psn_price_scale", "psn_update_costs",
+    "psn_dimacs_changes_size", "psn_dimacs_read_changes",
 ]
 
 
@@ -91,6 +92,9 @@ def load_library():
     lib.psn_settle_sources.argtypes = [vp, i64, vp, C.POINTER(i64)]
     lib.psn_update_caps.argtypes = [vp, i64, vp, vp]
     lib.psn_update_supplies.argtypes = [vp, i64, vp, vp]
+    lib.psn_update_costs.argtypes = [vp, i64, vp, vp]
+    lib.psn_dimacs_changes_size.argtypes = [C.c_char_p, C.POINTER(i64), C.POINTER(i64)]
+    lib.psn_dimacs_read_changes.argtypes = [C.c_char_p, i32, i64, vp, vp, vp, vp, vp, vp, vp]
     lib.psn_solve.argtypes = [vp, u32, C.POINTER(Result)]
     lib.psn_solve_batch.argtypes = [vp, i32, u32, i32, vp]
     lib.psn_get_flow.argtypes = [vp, vp]

@@ -792,6 +792,33 @@ int psn_update_caps(psn_ctx *c, int64_t count, const int64_t *arc_index, const i
     return PSN_OK;
 }
 
+int psn_update_costs(psn_ctx *c, int64_t count, const int64_t *arc_index, const int32_t *new_cost) {
+    if (!c || count < 0 || (count > 0 && (!arc_index || !new_cost))) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    if (count == 0) return PSN_OK;
+    for (int64_t i = 0; i < count; ++i) {
+        if (arc_index[i] < 0 || arc_index[i] >= c->m2 || new_cost[i] == INT32_MIN) return fail(c, PSN_EINVAL, "arc index or cost out of range");
+        const int64_t ac = new_cost[i] < 0 ? -(int64_t)new_cost[i] : new_cost[i];
+        const long double bound = 8.0L * (long double)c->n * (long double)(ac + 1) * (long double)(c->n + 1);
+        if (bound > 4.0e18L) return fail(c, PSN_EOVERFLOW, "n^2 * |cost| too large for int64 prices");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    char *d;
+    { const int rcs = stage(c, (size_t)count * (sizeof(i64) + sizeof(int)), &d); if (rcs != PSN_OK) return rcs; }
+    i64 *d_idx = (i64 *)d;
+    int *d_cost = (int *)(d_idx + count);
+    hipError_t e = hipMemcpyAsync(d_idx, arc_index, (size_t)count * sizeof(i64), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cost, new_cost, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const int grid = (int)std::min<long long>((count + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(k_scatter_costs, dim3(grid), dim3(kBlock), 0, c->stream, c->g, (long long)count, d_idx, d_cost, c->d_cost);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_update_costs", e);
+    return PSN_OK;
+}
+
 int psn_update_supplies(psn_ctx *c, int64_t count, const int32_t *vertex, const int64_t *new_supply) {
     if (!c || count < 0 || (count > 0 && (!vertex || !new_supply))) return fail(c, PSN_EINVAL, "null argument");
     if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");

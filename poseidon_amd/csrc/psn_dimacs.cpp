@@ -80,6 +80,7 @@ int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32
     FILE *f = std::fopen(path, "r");
     if (!f) return PSN_EINVAL;
     std::fill(supply, supply + n, (int64_t)0);
+    std::vector<int64_t> shift((size_t)n, 0);  // supply moved by lower bounds; added at the end, whatever order the lines come in
     int64_t base = 0, got = 0;
     char line[512];
     int rc = PSN_OK;
@@ -93,15 +94,87 @@ int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32
             if (std::sscanf(line, "a %lld %lld %lld %lld %lld", &u, &v, &lo, &hi, &c) != 5 || u < 1 || u > n || v < 1 || v > n ||
                 lo < 0 || hi < lo || hi - lo > INT32_MAX || c < -(long long)INT32_MAX || c > INT32_MAX || got >= m) { rc = PSN_EINVAL; break; }
             // a lower bound is flow that must be there: route it up front
-            supply[u - 1] -= lo; supply[v - 1] += lo; base += lo * c;
+            shift[(size_t)(u - 1)] -= lo; shift[(size_t)(v - 1)] += lo; base += lo * c;
             tail[got] = (int32_t)(u - 1); head[got] = (int32_t)(v - 1); cap[got] = (int32_t)(hi - lo); cost[got] = (int32_t)c;
             ++got;
         }
     }
     std::fclose(f);
     if (rc == PSN_OK && got != m) rc = PSN_EINVAL;
+    for (int32_t v = 0; v < n; ++v) supply[v] += shift[(size_t)v];
     if (base_cost) *base_cost = base;
     return rc;
+}
+
+// ---- change records: a second file that edits a problem already read
+//   x <tail> <head> <low> <cap> <cost> [<k>]   new capacity and cost of the k-th (default first) arc tail -> head
+//                                              of the problem file, counting parallel arcs in file order; low must be 0
+//   n <vertex> <supply>                         new supply of a vertex
+// Arcs are neither added nor removed (capacity 0 takes an arc out): the resident network keeps its
+// layout, which is what lets the device copy be edited in place and the solve warm-started.
+namespace {
+struct ChangeLine { char kind; long long a, b, lo, hi, c, k; };
+int parse_changes(const char *path, std::vector<ChangeLine> &out) {
+    FILE *f = std::fopen(path, "r");
+    if (!f) return PSN_EINVAL;
+    char line[512];
+    int rc = PSN_OK;
+    while (rc == PSN_OK && std::fgets(line, sizeof line, f)) {
+        ChangeLine ch{};
+        if (line[0] == 'x') {
+            ch.kind = 'x';
+            const int got = std::sscanf(line, "x %lld %lld %lld %lld %lld %lld", &ch.a, &ch.b, &ch.lo, &ch.hi, &ch.c, &ch.k);
+            if (got < 5 || ch.lo != 0 || ch.hi < 0 || ch.hi > INT32_MAX || ch.c < -(long long)INT32_MAX || ch.c > INT32_MAX || (got == 6 && ch.k < 0)) rc = PSN_EINVAL;
+            if (got < 6) ch.k = 0;
+            out.push_back(ch);
+        } else if (line[0] == 'n') {
+            ch.kind = 'n';
+            if (std::sscanf(line, "n %lld %lld", &ch.a, &ch.b) != 2) rc = PSN_EINVAL;
+            out.push_back(ch);
+        } else if (line[0] == 'a' || line[0] == 'p' || line[0] == 'r' || line[0] == 'd') {
+            rc = PSN_EINVAL;  // adding or removing arcs / vertices is not an in-place edit
+        }
+    }
+    std::fclose(f);
+    return rc;
+}
+}  // namespace
+
+int psn_dimacs_changes_size(const char *path, int64_t *n_arc_changes, int64_t *n_supply_changes) {
+    if (!path || !n_arc_changes || !n_supply_changes) return PSN_EINVAL;
+    std::vector<ChangeLine> ch;
+    const int rc = parse_changes(path, ch);
+    if (rc != PSN_OK) return rc;
+    *n_arc_changes = *n_supply_changes = 0;
+    for (const ChangeLine &c : ch) ++*(c.kind == 'x' ? n_arc_changes : n_supply_changes);
+    return PSN_OK;
+}
+
+int psn_dimacs_read_changes(const char *path, int32_t n, int64_t m, const int32_t *tail, const int32_t *head, int64_t *arc,
+                            int32_t *new_cap, int32_t *new_cost, int32_t *vertex, int64_t *new_supply) {
+    if (!path || n <= 0 || m < 0 || (m > 0 && (!tail || !head))) return PSN_EINVAL;
+    std::vector<ChangeLine> ch;
+    int rc = parse_changes(path, ch);
+    if (rc != PSN_OK) return rc;
+    // arcs of the problem by (tail, head), parallel arcs in file order
+    std::vector<int64_t> order((size_t)m);
+    for (int64_t i = 0; i < m; ++i) order[(size_t)i] = i;
+    auto key = [&](int64_t i) { return ((uint64_t)(uint32_t)tail[i] << 32) | (uint32_t)head[i]; };
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return key(x) != key(y) ? key(x) < key(y) : x < y; });
+    int64_t na = 0, ns = 0;
+    for (const ChangeLine &c : ch) {
+        if (c.kind == 'n') {
+            if (c.a < 1 || c.a > n || !vertex || !new_supply) return PSN_EINVAL;
+            vertex[ns] = (int32_t)(c.a - 1); new_supply[ns] = c.b; ++ns;
+            continue;
+        }
+        if (c.a < 1 || c.a > n || c.b < 1 || c.b > n || !arc || !new_cap || !new_cost) return PSN_EINVAL;
+        const uint64_t want = ((uint64_t)(uint32_t)(c.a - 1) << 32) | (uint32_t)(c.b - 1);
+        auto it = std::lower_bound(order.begin(), order.end(), want, [&](int64_t i, uint64_t w) { return key(i) < w; });
+        if (it == order.end() || key(*it) != want || (order.end() - it) <= c.k || key(*(it + c.k)) != want) return PSN_EINVAL;  // no such arc
+        arc[na] = *(it + c.k); new_cap[na] = (int32_t)c.hi; new_cost[na] = (int32_t)c.c; ++na;
+    }
+    return PSN_OK;
 }
 
 }  // extern "C"

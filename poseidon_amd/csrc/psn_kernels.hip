@@ -1587,6 +1587,15 @@ __global__ __launch_bounds__(kBlock) void k_scatter_caps(DevGraph g, long long c
         g.cap[a] = ncap[i] - flow;  // may go negative: repaired by k_clamp_flow
     }
 }
+// New cost of an arc (and its negation on the paired arc); flow and prices stay, a warm start
+// repairs whatever optimality conditions the change broke.
+__global__ __launch_bounds__(kBlock) void k_scatter_costs(DevGraph g, long long count, const i64 *idx, const int *ncost, int *mcost) {
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock) {
+        const unsigned a = (unsigned)idx[i];
+        mcost[a] = ncost[i];
+        mcost[g.rev[a]] = -ncost[i];
+    }
+}
 // After capacities shrank under a kept flow: cancel the flow that no longer fits.
 __global__ __launch_bounds__(kBlock) void k_clamp_flow(DevGraph g) {
     for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) {

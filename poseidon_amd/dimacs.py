@@ -35,6 +35,33 @@ def read(path: str):
     return {"n": n, "m": m, "tail": tail, "head": head, "cap": cap, "cost": cost, "supply": supply, "base_cost": base.value}
 
 
+def write_changes(path: str, arc_changes=(), supply_changes=(), comment: str = "libpsn change records"):
+    """arc_changes: iterable of (tail, head, cap, cost[, k]) with 0-based ids, k = which of the parallel
+    arcs tail -> head in problem-file order; supply_changes: iterable of (vertex, supply)."""
+    with open(path, "w") as f:
+        f.write(f"c {comment}\n")
+        for v, sup in supply_changes:
+            f.write(f"n {int(v) + 1} {int(sup)}\n")
+        for rec in arc_changes:
+            t, h, cp, cs = rec[:4]
+            k = f" {int(rec[4])}" if len(rec) > 4 else ""
+            f.write(f"x {int(t) + 1} {int(h) + 1} 0 {int(cp)} {int(cs)}{k}\n")
+
+
+def read_changes(path: str, problem: dict):
+    """Change records resolved against a problem read by read(): -> dict(arc, cap, cost, vertex,
+    supply) where arc[i] indexes the problem's arc list."""
+    lib = _lib.load_library()
+    na, ns = C.c_int64(), C.c_int64()
+    _lib.check(lib.psn_dimacs_changes_size(path.encode(), C.byref(na), C.byref(ns)))
+    arc = np.empty(na.value, np.int64); cap = np.empty(na.value, np.int32); cost = np.empty(na.value, np.int32)
+    vertex = np.empty(ns.value, np.int32); supply = np.empty(ns.value, np.int64)
+    tail = np.ascontiguousarray(problem["tail"], np.int32); head = np.ascontiguousarray(problem["head"], np.int32)
+    _lib.check(lib.psn_dimacs_read_changes(path.encode(), int(problem["n"]), int(problem["m"]), tail.ctypes.data, head.ctypes.data,
+                                           arc.ctypes.data, cap.ctypes.data, cost.ctypes.data, vertex.ctypes.data, supply.ctypes.data))
+    return {"arc": arc, "cap": cap, "cost": cost, "vertex": vertex, "supply": supply}
+
+
 def csr_from_arcs(n: int, tail, head, cap, cost):
     """-> (row_off, head, cap, cost, rev, fwd_pos) residual CSR of an arc list."""
     lib = _lib.load_library()

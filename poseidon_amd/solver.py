@@ -99,6 +99,11 @@ class Solver:
         new_cap = np.ascontiguousarray(new_cap, np.int32)
         self._chk(self._lib.psn_update_caps(self._ctx, arc_index.shape[0], _vp(arc_index), _vp(new_cap)))
 
+    def update_costs(self, arc_index, new_cost):
+        arc_index = np.ascontiguousarray(arc_index, np.int64)
+        new_cost = np.ascontiguousarray(new_cost, np.int32)
+        self._chk(self._lib.psn_update_costs(self._ctx, arc_index.shape[0], _vp(arc_index), _vp(new_cost)))
+
     def set_admission_mask(self, layout, allowed):
         """allowed: bool [E, N] (class e may use machine m) or None to lift the mask."""
         if allowed is None:

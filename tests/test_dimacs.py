@@ -83,3 +83,43 @@ def test_external_solver_hook(tmp_path, monkeypatch):
     monkeypatch.setenv("PSN_EXT_SOLVER", str(exe))
     cost, secs = dimacs.run_external_solver(str(p))
     assert cost == 14 and secs >= 0
+
+
+def test_supply_lines_after_arc_lines_keep_lower_bound_shifts(tmp_path):
+    """An 'n' line that comes after the 'a' lines must not wipe out what lower bounds moved into the supplies."""
+    a = tmp_path / "a.min"
+    b = tmp_path / "b.min"
+    a.write_text("p min 3 2\nn 1 5\nn 3 -5\na 1 2 2 6 1\na 2 3 0 6 1\n")
+    b.write_text("p min 3 2\na 1 2 2 6 1\na 2 3 0 6 1\nn 1 5\nn 3 -5\n")
+    da, db = dimacs.read(str(a)), dimacs.read(str(b))
+    assert da["supply"].tolist() == db["supply"].tolist() == [3, 2, -5]
+    assert da["base_cost"] == db["base_cost"] == 2 and da["cap"].tolist() == [4, 6]
+
+
+def test_change_records_resolve_against_the_problem(tmp_path):
+    p = tmp_path / "tiny.min"
+    p.write_text(TINY)
+    d = dimacs.read(str(p))
+    ch = tmp_path / "tiny.chg"
+    dimacs.write_changes(str(ch), arc_changes=[(1, 3, 1, 3), (0, 2, 2, 9)], supply_changes=[(0, 3), (3, -3)])
+    c = dimacs.read_changes(str(ch), d)
+    assert c["arc"].tolist() == [3, 1] and c["cap"].tolist() == [1, 2] and c["cost"].tolist() == [3, 9]
+    assert c["vertex"].tolist() == [0, 3] and c["supply"].tolist() == [3, -3]
+    cap, cost, supply = d["cap"].copy(), d["cost"].copy(), d["supply"].copy()
+    cap[c["arc"]], cost[c["arc"]] = c["cap"], c["cost"]
+    supply[c["vertex"]] = c["supply"]
+    # 3 units: 1-2-3-4 (cost 4, cap 2), then 1-2-4 (cost 5, cap 1): 8 + 5 = 13; 1-3 now costs 9
+    assert _solve(4, d["tail"], d["head"], cap, cost, supply) == 13
+    # parallel arcs are told apart by their position in the problem file
+    q = tmp_path / "par.min"
+    q.write_text("p min 2 3\nn 1 2\nn 2 -2\na 1 2 0 1 5\na 1 2 0 1 7\na 1 2 0 1 9\n")
+    dq = dimacs.read(str(q))
+    chq = tmp_path / "par.chg"
+    dimacs.write_changes(str(chq), arc_changes=[(0, 1, 1, 1, 2)])
+    assert dimacs.read_changes(str(chq), dq)["arc"].tolist() == [2]
+    # records that name no arc of the problem, add arcs, or carry a lower bound are refused
+    for text in ("x 1 4 0 1 1\n", "a 1 2 0 1 1\n", "x 1 2 1 4 2\n", "x 1 2 0 4 2 7\n", "n 9 1\n"):
+        bad = tmp_path / "bad.chg"
+        bad.write_text(text)
+        with pytest.raises(_lib.PsnError):
+            dimacs.read_changes(str(bad), d)
