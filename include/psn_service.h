@@ -148,9 +148,27 @@ int psn_svc_node_labels(psn_svc *svc, const char *resource_uuid, const char *con
  * tasks known to the service; feeds the cost model, where the requests of the tasks the service
  * has running on the machine are added to it.  Reply as for NodeUpdated. */
 int psn_svc_add_node_stats(psn_svc *svc, const char *resource_uuid, int64_t used_cpu_millicores, int64_t used_ram_kb);
-/* AddTaskStats (:40): accepted and ignored (the client ignores the reply,
- * /root/reference/pkg/firmament/firmament_client.go:183-188). */
+/* AddNodeStats with the fields of the message itself (ResourceStats,
+ * /root/reference/pkg/firmament/resource_stats.proto:22-59, filled at
+ * /root/reference/pkg/stats/stats.go:60-75): per-CPU (or whole-node, one entry) capacity in
+ * millicores and utilisation, memory capacity in Kb and utilisation.  A utilisation up to 1 is
+ * read as a fraction of the capacity (what the message says), a larger one as a quantity (what
+ * the reference's vectors carry, /root/reference/pkg/stats/stats_test.go:100-127).  The figure
+ * measures the whole machine, the tasks the service runs there included; their share (observed
+ * usage where AddTaskStats reported it, the request otherwise) is taken out to get the usage by
+ * everything else, to which the requests of the running tasks are then added as for
+ * psn_svc_add_node_stats.  A later psn_svc_add_node_stats replaces the measurement. */
+int psn_svc_add_node_stats_raw(psn_svc *svc, const char *resource_uuid, int32_t n_cpus, const int64_t *cpu_capacity,
+                               const double *cpu_utilization, int64_t mem_capacity, double mem_utilization);
+/* AddTaskStats (:40).  psn_svc_add_task_stats only acknowledges (the client ignores the reply,
+ * /root/reference/pkg/firmament/firmament_client.go:183-188); the _raw form records the task's
+ * observed cpu_usage (millicores) and mem_usage (Kb) (TaskStats,
+ * /root/reference/pkg/firmament/task_stats.proto:22-50, filled at
+ * /root/reference/pkg/stats/stats.go:33-57).  What a running task holds on its machine stays
+ * its request (that is what is reserved for it); the observed usage tells how much of a measured
+ * machine figure is the task's own. */
 int psn_svc_add_task_stats(psn_svc *svc, uint64_t task_uid);
+int psn_svc_add_task_stats_raw(psn_svc *svc, uint64_t task_uid, int64_t cpu_usage_millicores, int64_t mem_usage_kb);
 /* Check (:44). */
 int psn_svc_check(const psn_svc *svc);
 

@@ -36,6 +36,7 @@ EXPORTS = [
     "psn_svc_task_submitted_sel", "psn_svc_node_labels", "psn_svc_export_mask", "psn_svc_network_size", "psn_svc_export_network", "psn_svc_task_placement", "psn_svc_solver",
     "psn_gather_placements", "psn_debug_alloc_count", "psn_get_placements_device_noalloc", "psn_price_scale", "psn_update_costs",
     "psn_dimacs_changes_size", "psn_dimacs_read_changes",
+    "psn_svc_add_node_stats_raw", "psn_svc_add_task_stats_raw",
 ]
 
 

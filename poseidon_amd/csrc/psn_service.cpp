@@ -44,6 +44,7 @@ struct Machine {
     std::string uuid;
     std::map<std::string, std::string> labels;
     i64 cap_cpu = 0, cap_mem = 0, used_cpu = 0, used_mem = 0;
+    i64 meas_cpu = -1, meas_mem = -1;          // measured usage of the whole machine (ResourceStats), -1: none reported
     i64 committed_cpu = 0, committed_mem = 0;  // requests of the tasks running here (keep-running mode)
     int running = 0;                           // how many they are: each holds one of the machine's slots
     bool live = false;
@@ -75,6 +76,7 @@ struct Task {
     int machine = -1;            // placement after the last round
     uint32_t machine_gen = 0;
     bool pinned = false;         // running on `machine` and therefore outside the network (keep-running mode)
+    i64 obs_cpu = -1, obs_mem = -1;  // observed usage (TaskStats), -1: none reported
     i64 cpu = 0, ram = 0;
 };
 struct Delta { uint64_t uid; int32_t type; int machine; };
@@ -128,6 +130,11 @@ struct psn_svc {
     // results
     std::vector<Delta> deltas;
     psn_svc_stats st{};
+    // usage of each machine by things the service does not manage, as the cost model and the admission
+    // check see it; follows the AddNodeStats figures, or the measured whole-machine usage less what the
+    // service's own running tasks use there
+    std::vector<i64> ext_cpu, ext_mem;
+    bool any_measured = false;
 
     int fail(int code, const std::string &what) { err = what; return code; }
 
@@ -473,8 +480,30 @@ struct psn_svc {
         return PSN_OK;
     }
 
+    // External usage per machine.  A measured figure covers everything on the machine, the tasks the
+    // service runs there included; their share is taken out again: the observed usage of a task where
+    // TaskStats reported one, its request otherwise (requests stay what is reserved for a running task).
+    void refresh_external() {
+        ext_cpu.assign(machines.size(), 0); ext_mem.assign(machines.size(), 0);
+        std::vector<i64> own_cpu, own_mem;
+        if (any_measured) {
+            own_cpu.assign(machines.size(), 0); own_mem.assign(machines.size(), 0);
+            for (auto &kv : tasks) {
+                const Task &t = kv.second;
+                if (!t.pinned || !on_its_machine(t)) continue;
+                own_cpu[(size_t)t.machine] += t.obs_cpu >= 0 ? t.obs_cpu : t.cpu;
+                own_mem[(size_t)t.machine] += t.obs_mem >= 0 ? t.obs_mem : t.ram;
+            }
+        }
+        for (size_t m = 0; m < machines.size(); ++m) {
+            const Machine &mc = machines[m];
+            ext_cpu[m] = mc.meas_cpu >= 0 ? std::max<i64>(0, mc.meas_cpu - own_cpu[m]) : mc.used_cpu;
+            ext_mem[m] = mc.meas_mem >= 0 ? std::max<i64>(0, mc.meas_mem - own_mem[m]) : mc.used_mem;
+        }
+    }
     void cost_inputs(std::vector<i64> &cc, std::vector<i64> &cm, std::vector<i64> &uc, std::vector<i64> &um, std::vector<i64> &rc,
-                     std::vector<i64> &rm) const {
+                     std::vector<i64> &rm) {
+        refresh_external();
         cc.assign((size_t)N, kDeadQuantity); cm.assign((size_t)N, kDeadQuantity);
         uc.assign((size_t)N, kDeadQuantity); um.assign((size_t)N, kDeadQuantity);
         for (size_t m = 0; m < machines.size() && m < (size_t)N; ++m) {
@@ -483,7 +512,7 @@ struct psn_svc {
             cc[m] = mc.cap_cpu; cm[m] = mc.cap_mem;
             // usage = what the statistics report for things the service does not manage + the requests
             // of the tasks it has running there
-            uc[m] = std::min(mc.used_cpu + mc.committed_cpu, mc.cap_cpu); um[m] = std::min(mc.used_mem + mc.committed_mem, mc.cap_mem);
+            uc[m] = std::min(ext_cpu[m] + mc.committed_cpu, mc.cap_cpu); um[m] = std::min(ext_mem[m] + mc.committed_mem, mc.cap_mem);
         }
         rc.assign((size_t)E, 1); rm.assign((size_t)E, 1);
         for (size_t e = 0; e < classes.size() && e < (size_t)E; ++e) { rc[e] = classes[e].cpu; rm[e] = classes[e].ram; }
@@ -637,6 +666,7 @@ int psn_svc_node_added(psn_svc *s, const char *uuid, int64_t cpu, int64_t ram) {
     Machine &mc = s->machines[(size_t)m];
     mc.uuid = uuid; mc.cap_cpu = cpu; mc.cap_mem = ram; mc.used_cpu = mc.used_mem = 0; mc.live = true; ++mc.gen;
     mc.committed_cpu = mc.committed_mem = 0; mc.running = 0;
+    mc.meas_cpu = mc.meas_mem = -1;
     s->machine_by_uuid[uuid] = m;
     mc.labels.clear();
     if (s->laid_out && m < s->N) { s->set_cap(s->machine_sink_arc(m), s->sink_capacity(m)); s->reprice = true; s->mask_machine(m); }
@@ -659,8 +689,50 @@ int psn_svc_add_node_stats(psn_svc *s, const char *uuid, int64_t used_cpu, int64
     auto it = s->machine_by_uuid.find(uuid);
     if (it == s->machine_by_uuid.end()) return PSN_NODE_NOT_FOUND;
     Machine &mc = s->machines[(size_t)it->second];
-    if (mc.used_cpu != used_cpu || mc.used_mem != used_ram) { mc.used_cpu = used_cpu; mc.used_mem = used_ram; s->reprice = true; }
+    if (mc.used_cpu != used_cpu || mc.used_mem != used_ram || mc.meas_cpu >= 0 || mc.meas_mem >= 0) {
+        mc.used_cpu = used_cpu; mc.used_mem = used_ram; mc.meas_cpu = mc.meas_mem = -1; s->reprice = true;
+    }
     return PSN_NODE_UPDATED_OK;
+}
+
+// A utilisation figure of ResourceStats as a quantity: the message describes it as a fraction of the
+// capacity (/root/reference/pkg/firmament/resource_stats.proto:36-39,56-59), the reference's own
+// vectors carry absolute quantities (/root/reference/pkg/stats/stats_test.go:100-127: utilisation
+// 2000.0 of capacity 10000).  Values up to 1 are taken as fractions, larger ones as quantities.
+static i64 stats_quantity(double utilization, i64 capacity) {
+    if (!(utilization > 0)) return 0;
+    const double q = utilization <= 1.0 ? utilization * (double)capacity : utilization;
+    const double capped = std::min(q, (double)capacity);
+    return (i64)(capped + 0.5);
+}
+
+int psn_svc_add_node_stats_raw(psn_svc *s, const char *uuid, int32_t n_cpus, const int64_t *cpu_capacity, const double *cpu_utilization,
+                               int64_t mem_capacity, double mem_utilization) {
+    if (!s || bad_uuid(uuid) || n_cpus < 0 || (n_cpus > 0 && (!cpu_capacity || !cpu_utilization)) || mem_capacity < 0)
+        return s ? s->fail(PSN_EINVAL, "bad machine statistics") : PSN_EINVAL;
+    auto it = s->machine_by_uuid.find(uuid);
+    if (it == s->machine_by_uuid.end()) return PSN_NODE_NOT_FOUND;
+    Machine &mc = s->machines[(size_t)it->second];
+    i64 cpu = 0;
+    for (int32_t i = 0; i < n_cpus; ++i) {  // one entry per CPU, or one for the whole node as the reference sends it (stats.go:60-66)
+        if (cpu_capacity[i] < 0) return s->fail(PSN_EINVAL, "bad machine statistics");
+        cpu += stats_quantity(cpu_utilization[i], cpu_capacity[i]);
+    }
+    const i64 mem = stats_quantity(mem_utilization, mem_capacity);
+    if (mc.meas_cpu != cpu || mc.meas_mem != mem) { mc.meas_cpu = cpu; mc.meas_mem = mem; s->any_measured = true; s->reprice = true; }
+    return PSN_NODE_UPDATED_OK;
+}
+
+int psn_svc_add_task_stats_raw(psn_svc *s, uint64_t uid, int64_t cpu_usage, int64_t mem_usage) {
+    if (!s || cpu_usage < 0 || mem_usage < 0) return s ? s->fail(PSN_EINVAL, "bad task statistics") : PSN_EINVAL;
+    auto it = s->tasks.find(uid);
+    if (it == s->tasks.end()) return PSN_TASK_NOT_FOUND;
+    Task &t = it->second;
+    if (t.obs_cpu != cpu_usage || t.obs_mem != mem_usage) {
+        t.obs_cpu = cpu_usage; t.obs_mem = mem_usage;
+        if (t.pinned && s->any_measured) s->reprice = true;  // its share of a measured machine changed
+    }
+    return PSN_TASK_UPDATED_OK;
 }
 
 static int node_leaves(psn_svc *s, const char *uuid, int ok_code) {
@@ -913,11 +985,12 @@ int64_t psn_svc_schedule(psn_svc *s) {
     std::vector<i64> free_cpu, free_mem;
     std::vector<int> free_slot;
     if (keep) {
+        s->refresh_external();
         free_cpu.resize(s->machines.size()); free_mem.resize(s->machines.size()); free_slot.resize(s->machines.size());
         for (size_t m = 0; m < s->machines.size(); ++m) {
             const Machine &mc = s->machines[m];
-            free_cpu[m] = mc.cap_cpu - std::min(mc.used_cpu + mc.committed_cpu, mc.cap_cpu);
-            free_mem[m] = mc.cap_mem - std::min(mc.used_mem + mc.committed_mem, mc.cap_mem);
+            free_cpu[m] = mc.cap_cpu - std::min(s->ext_cpu[m] + mc.committed_cpu, mc.cap_cpu);
+            free_mem[m] = mc.cap_mem - std::min(s->ext_mem[m] + mc.committed_mem, mc.cap_mem);
             free_slot[m] = s->sink_capacity((int)m);
         }
     }

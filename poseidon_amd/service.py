@@ -74,6 +74,8 @@ def _bind(lib):
     lib.psn_svc_node_added.argtypes = [vp, cp, i64, i64]
     lib.psn_svc_node_updated.argtypes = [vp, cp, i64, i64]
     lib.psn_svc_add_node_stats.argtypes = [vp, cp, i64, i64]
+    lib.psn_svc_add_node_stats_raw.argtypes = [vp, cp, i32, vp, vp, i64, C.c_double]
+    lib.psn_svc_add_task_stats_raw.argtypes = [vp, u64, i64, i64]
     lib.psn_svc_node_failed.argtypes = [vp, cp]
     lib.psn_svc_node_removed.argtypes = [vp, cp]
     lib.psn_svc_check.argtypes = [vp]
@@ -153,8 +155,21 @@ class SchedulerService:
     def TaskRemoved(self, uid: int):
         return self._reply(self._lib.psn_svc_task_removed(self._svc, uid), TaskReplyType)
 
-    def AddTaskStats(self, uid: int):
-        return self._reply(self._lib.psn_svc_add_task_stats(self._svc, uid), TaskReplyType)
+    def AddTaskStats(self, uid: int, cpu_usage: int | None = None, mem_usage: int | None = None):
+        """TaskStats (/root/reference/pkg/firmament/task_stats.proto:22-50): cpu_usage in millicores,
+        mem_usage in Kb; without them the call only acknowledges."""
+        if cpu_usage is None and mem_usage is None:
+            return self._reply(self._lib.psn_svc_add_task_stats(self._svc, uid), TaskReplyType)
+        return self._reply(self._lib.psn_svc_add_task_stats_raw(self._svc, uid, int(cpu_usage or 0), int(mem_usage or 0)), TaskReplyType)
+
+    def AddNodeStatsRaw(self, uuid: str, cpus_stats, mem_capacity: int, mem_utilization: float):
+        """ResourceStats as the message carries it (/root/reference/pkg/firmament/resource_stats.proto:22-59):
+        cpus_stats = [(cpu_capacity millicores, cpu_utilization), ...], memory capacity in Kb and utilisation."""
+        n = len(cpus_stats)
+        caps = (C.c_int64 * max(1, n))(*[int(c) for c, _ in cpus_stats])
+        utils = (C.c_double * max(1, n))(*[float(u) for _, u in cpus_stats])
+        return self._reply(self._lib.psn_svc_add_node_stats_raw(self._svc, uuid.encode(), n, caps, utils, int(mem_capacity),
+                                                                float(mem_utilization)), NodeReplyType)
 
     # ---- node RPCs
     def NodeAdded(self, uuid: str, cpu_millicores: int, ram_kb: int):

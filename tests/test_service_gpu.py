@@ -402,3 +402,25 @@ def test_two_classes_cannot_overcommit_a_machine_in_one_round():
         assert s.TaskCompleted(d1[0].task_id) == TR.TASK_COMPLETED_OK
         d2 = s.Schedule()
         assert [(d.task_id, d.type) for d in d2] == [(other, CT.PLACE)]
+
+
+def test_measured_machine_usage_excludes_the_running_tasks_own_share():
+    """A measured whole-machine figure (ResourceStats) includes what the service's own running tasks use;
+    their share (observed usage where TaskStats reported it, else the request) is taken out before the
+    requests of the running tasks are added back as what is reserved."""
+    with pa.SchedulerService(device=0) as s:
+        assert s.NodeAdded(machine_uuid(0), 10000, 1000000) == NR.NODE_ADDED_OK
+        assert s.TaskSubmitted(1, job_uuid(0), 100, 1000) == TR.TASK_SUBMITTED_OK
+        assert s.TaskSubmitted(2, job_uuid(0), 400, 4000) == TR.TASK_SUBMITTED_OK
+        assert len(s.Schedule()) == 2 and s.stats().tasks_running == 2
+        assert s.AddTaskStats(1, cpu_usage=30, mem_usage=500) == TR.TASK_UPDATED_OK   # task 2 reports nothing
+        assert s.AddNodeStatsRaw(machine_uuid(0), [(10000, 2000.0)], 1000000, 100000.0) == NR.NODE_UPDATED_OK
+        assert s.TaskSubmitted(3, job_uuid(0), 100, 1000) == TR.TASK_SUBMITTED_OK     # something pending: a network exists
+        ex = s.export_network()
+        # external = 2000 - (30 + 400) ; reserved = 100 + 400
+        assert int(ex["used_cpu"][0]) == (2000 - 430) + 500
+        assert int(ex["used_mem"][0]) == (100000 - (500 + 4000)) + 5000
+        g, _ = exported_graph(s)
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        d = s.Schedule()
+        assert rc == 0 and tc == s.stats().total_cost and [x.task_id for x in d] == [3]

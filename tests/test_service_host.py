@@ -177,3 +177,31 @@ def test_random_rpc_sequences_keep_the_network_right(seed):
             rc, tc, _, _, _ = capi.cost_scaling(g)
             assert rc == 0 and tc == model_cost(st.machines, st.tasks, shapes), (seed, burst)
         assert s.stats().rebuilds >= 2  # the small initial capacities were outgrown on the way
+
+
+def test_resource_stats_fields_map_to_machine_usage():
+    """AddNodeStats with the fields of the message: the reference's converter vectors
+    (/root/reference/pkg/stats/stats_test.go:100-127: CPU capacity 10000 / utilisation 2000.0, memory
+    capacity 1000000 / utilisation 100000.0) give 2000 millicores and 100000 Kb in use; the same
+    figures as fractions of the capacity (what the message text describes) give the same."""
+    with pa.SchedulerService(device=-1) as s:
+        for m in range(3):
+            assert s.NodeAdded(machine_uuid(m), 10000, 1000000) == NR.NODE_ADDED_OK
+        assert s.AddNodeStatsRaw(machine_uuid(0), [(10000, 2000.0)], 1000000, 100000.0) == NR.NODE_UPDATED_OK
+        assert s.AddNodeStatsRaw(machine_uuid(1), [(10000, 0.2)], 1000000, 0.1) == NR.NODE_UPDATED_OK
+        # per-CPU entries add up; a figure above the capacity is cut to it
+        assert s.AddNodeStatsRaw(machine_uuid(2), [(2500, 0.5), (2500, 2000.0), (2500, 9999.0), (2500, 0.0)], 1000000, 5e9) \
+            == NR.NODE_UPDATED_OK
+        assert s.AddNodeStatsRaw("no-such-node", [(1, 0.5)], 1, 0.5) == NR.NODE_NOT_FOUND
+        assert s.TaskSubmitted(1, "job-0", 100, 1000) == TR.TASK_SUBMITTED_OK
+        # the reference's TaskStats vector: cpu_usage 30, mem_usage 500 (stats_test.go:41-46)
+        assert s.AddTaskStats(1, cpu_usage=30, mem_usage=500) == TR.TASK_UPDATED_OK
+        assert s.AddTaskStats(2, cpu_usage=30, mem_usage=500) == TR.TASK_NOT_FOUND
+        assert s.AddTaskStats(1) == TR.TASK_UPDATED_OK
+        ex = s.export_network()
+        assert ex["used_cpu"][:3].tolist() == [2000, 2000, 1250 + 2000 + 2500]
+        assert ex["used_mem"][:3].tolist() == [100000, 100000, 1000000]
+        # plain AddNodeStats replaces a measurement
+        assert s.AddNodeStats(machine_uuid(0), 700, 7000) == NR.NODE_UPDATED_OK
+        ex = s.export_network()
+        assert (int(ex["used_cpu"][0]), int(ex["used_mem"][0])) == (700, 7000)
