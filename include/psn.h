@@ -110,6 +110,32 @@ int psn_upload_csr(psn_ctx *ctx, int32_t n, int64_t m2, const int64_t *row_off,
                    const int32_t *head, const int32_t *cap, const int32_t *cost,
                    const int32_t *rev, const int64_t *supply);
 
+/* The same hand-over for a scheduling network, built on the device: the residual CSR that
+ * psn_build_network (include/psn_builder.h) would lay out for this layout and these tasks is
+ * written straight into the context, arc for arc the same, from two words per task (class and
+ * job index) instead of being assembled on the host and copied (300 MB at 10 000 machines).
+ * Machine -> sink arcs get capacity `slots`, task -> unscheduled arcs cost `unsched_cost`; slot
+ * arcs are left unpriced for psn_eval_costs, whose ec_arc_base argument is returned in
+ * ec_arc_base_out (n_classes entries, may be NULL).  This is the flow-graph construction that
+ * Firmament does from the TaskSubmitted / NodeAdded stream
+ * (/root/reference/pkg/firmament/firmament_scheduler.proto:26,31) before a Schedule call. */
+int psn_build_network_device(psn_ctx *ctx, const psn_layout *layout, int32_t slots, int32_t unsched_cost,
+                             const int32_t *task_class, const int32_t *task_job, int64_t *ec_arc_base_out);
+
+/* psn_build_network_device for a network laid out with head-room, the way a service keeps it
+ * resident between rounds: class e's row has room_class[e] reverse places for member tasks before
+ * its slot arcs, job j's row room_job[j] before its arc to the sink, and there are n_tasks task
+ * slots; n_attached tasks are given by slot, class, job and the place each takes in its class row
+ * and job row (all distinct).  Places and slots that nobody takes are placeholders (self-loops
+ * paired with themselves, capacity 0) which psn_patch_arcs can hand to tasks that arrive later.
+ * Machine m's arc to the sink gets capacity machine_sink_cap[m], job j's job_sink_cap[j]. */
+int psn_build_network_rooms_device(psn_ctx *ctx, const psn_layout *layout, int32_t unsched_cost,
+                                   const int32_t *room_class, const int32_t *room_job,
+                                   const int32_t *machine_sink_cap, const int32_t *job_sink_cap,
+                                   int64_t n_attached, const int32_t *task_slot, const int32_t *task_class,
+                                   const int32_t *task_job, const int32_t *place_class, const int32_t *place_job,
+                                   int64_t *ec_arc_base_out);
+
 /* CPU/memory arc-cost model on the device: prices every (task class e, machine m,
  * slot k) arc of the uploaded network in place (cost and capacity of the forward
  * arc, -cost / 0 on its reverse).  ec_arc_base[e] is the index of class e's first
@@ -209,6 +235,11 @@ int psn_price_scale(psn_ctx *ctx, int64_t *scale);
 int psn_get_residual(psn_ctx *ctx, int32_t *cap /* m2 */);
 int psn_get_prices(psn_ctx *ctx, int64_t *price /* n */);
 int psn_get_costs(psn_ctx *ctx, int32_t *cost /* m2 */, int32_t *cap_orig /* m2 */);
+/* The structure of the resident network as psn_upload_csr takes it: heads and paired-arc
+ * indices (m2 entries each), row offsets (n + 1) and supplies (n); any pointer may be NULL.
+ * With psn_get_costs this reads back everything psn_build_network_device wrote. */
+int psn_get_structure(psn_ctx *ctx, int32_t *head /* m2 */, int32_t *rev /* m2 */);
+int psn_get_rows(psn_ctx *ctx, int64_t *row_off /* n + 1 */, int64_t *supply /* n */);
 int psn_get_placements(psn_ctx *ctx, const psn_layout *layout, int32_t *task_to_machine /* P */);
 
 /* Same as psn_get_placements but into caller-owned device memory (int32[P]) on this

@@ -105,6 +105,7 @@ typedef struct psn_svc_stats {
     int64_t total_cost;
     int32_t last_round_warm;
     int64_t tasks_running;   /* tasks that hold a machine outside the network (reschedule_running = 0) */
+    double total_ms;         /* last Schedule from entry to return, host clock */
     int64_t tasks_deferred;  /* last Schedule: placements not admitted because the request no longer fitted next
                                 to what other classes were given on that machine in the same round */
 } psn_svc_stats;

@@ -36,7 +36,7 @@ EXPORTS = [
     "psn_svc_task_submitted_sel", "psn_svc_node_labels", "psn_svc_export_mask", "psn_svc_network_size", "psn_svc_export_network", "psn_svc_task_placement", "psn_svc_solver",
     "psn_gather_placements", "psn_debug_alloc_count", "psn_get_placements_device_noalloc", "psn_price_scale", "psn_update_costs",
     "psn_dimacs_changes_size", "psn_dimacs_read_changes",
-    "psn_svc_add_node_stats_raw", "psn_svc_add_task_stats_raw",
+    "psn_svc_add_node_stats_raw", "psn_svc_add_task_stats_raw", "psn_build_network_device", "psn_get_structure", "psn_get_rows", "psn_build_network_rooms_device",
 ]
 
 
@@ -86,6 +86,7 @@ def load_library():
     lib.psn_destroy.argtypes = [vp]
     lib.psn_destroy.restype = None
     lib.psn_upload_csr.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp]
+    lib.psn_build_network_device.argtypes = [vp, C.POINTER(Layout), i32, i32, vp, vp, vp]
     lib.psn_eval_costs.argtypes = [vp, C.POINTER(Layout), vp, vp, vp, vp, vp, vp, vp]
     lib.psn_reprice_costs.argtypes = [vp, C.POINTER(Layout), vp, vp, vp, vp, vp, vp, vp]
     lib.psn_set_admission_mask.argtypes = [vp, C.POINTER(Layout), vp]
@@ -102,6 +103,8 @@ def load_library():
     lib.psn_get_residual.argtypes = [vp, vp]
     lib.psn_get_prices.argtypes = [vp, vp]
     lib.psn_get_costs.argtypes = [vp, vp, vp]
+    lib.psn_get_structure.argtypes = [vp, vp, vp]
+    lib.psn_get_rows.argtypes = [vp, vp, vp]
     lib.psn_price_scale.argtypes = [vp, C.POINTER(i64)]
     lib.psn_get_placements.argtypes = [vp, C.POINTER(Layout), vp]
     lib.psn_get_placements_device.argtypes = [vp, C.POINTER(Layout), vp]

@@ -437,27 +437,17 @@ void psn_destroy(psn_ctx *c) {
     delete c;
 }
 
-int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, const int32_t *head, const int32_t *cap,
-                   const int32_t *cost, const int32_t *rev, const int64_t *supply) {
-    if (!c) return PSN_EINVAL;
-    const bool dbg_up = std::getenv("PSN_DEBUG_UPLOAD") != nullptr;
-    auto now_up = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double tu0 = now_up();
-    if (n <= 0 || n >= kMaxVertices || m2 < 0 || m2 >= (int64_t)0x7FFFFFF0 || !row_off || !supply || (m2 > 0 && (!head || !cap || !cost || !rev)))
-        return fail(c, PSN_EINVAL, "null or out-of-range argument");
-    // ---- validate: offsets and supplies here, the arcs on the device once they are there (the solver
-    // kernels only ever see a network that passed; a rejected upload leaves the context empty)
+// Everything about a network that follows from its row offsets: vertex classes, hubs and their
+// segments, every device buffer, and the small per-vertex tables uploaded.  The arc arrays
+// (head, cost, rev, ocap, cap, supply) are left for the caller to fill on the stream.
+static int setup_rows(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off) {
+    if (n <= 0 || n >= kMaxVertices || m2 < 0 || m2 >= (int64_t)0x7FFFFFF0 || !row_off) return fail(c, PSN_EINVAL, "null or out-of-range argument");
     if (row_off[0] != 0 || row_off[n] != m2) return fail(c, PSN_EINVAL, "row_off[0] != 0 or row_off[n] != m2");
     for (int32_t v = 0; v < n; ++v)
         if (row_off[v + 1] < row_off[v]) return fail(c, PSN_EINVAL, "row_off not monotone");
-    int64_t ssum = 0;
-    for (int32_t v = 0; v < n; ++v) ssum += supply[v];
-    if (ssum != 0) return fail(c, PSN_EINFEASIBLE, "supplies do not sum to zero");
-    const double tu1 = now_up();
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_graph_buffers(c);
-    const double tu2 = now_up();
     c->n = n;
     c->m2 = m2;
     // ---- classify vertices by degree
@@ -526,7 +516,6 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     g.row = d_row; g.head = d_head; g.cost = c->d_cost; g.rev = d_rev; g.tail = d_tail; g.ocap = c->d_ocap; g.cls = d_cls;
     g.hub_of = d_hub_of; g.hub_vertex = d_hub_vertex; g.nhubs = nhubs;
     g.hub_row0 = d_hub_row0; g.hub_seg0 = d_hub_seg0; g.seg1_of = d_seg1_of; g.n_hub_segs = n_hub_segs;
-    const double tu3 = now_up();
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(d_row, row.data(), sizeof(unsigned) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_cls, cls.data(), (size_t)n, hipMemcpyHostToDevice, s));
@@ -535,23 +524,44 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     HIPCHK(c, hipMemcpyAsync(d_hub_row0, hub_row0.data(), sizeof(unsigned) * (size_t)kMaxHubs, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_hub_seg0, hub_seg0.data(), sizeof(int) * (size_t)kMaxHubs, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_seg1_of, seg1_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(d_head, head, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(g.price, 0, sizeof(i64) * (size_t)n, s));
+    if (m2 > 0) hipLaunchKernelGGL(k_fill_tail, dim3(kGrid), dim3(kBlock), 0, s, d_row, (int)n, (unsigned)m2, d_tail);
+    HIPCHK(c, hipStreamSynchronize(s));  // the staging vectors above die at return
+    return PSN_OK;
+}
+
+int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, const int32_t *head, const int32_t *cap,
+                   const int32_t *cost, const int32_t *rev, const int64_t *supply) {
+    if (!c) return PSN_EINVAL;
+    const bool dbg_up = std::getenv("PSN_DEBUG_UPLOAD") != nullptr;
+    auto now_up = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tu0 = now_up();
+    if (n <= 0 || !row_off || !supply || (m2 > 0 && (!head || !cap || !cost || !rev)))
+        return fail(c, PSN_EINVAL, "null or out-of-range argument");
+    // ---- validate: offsets and supplies here, the arcs on the device once they are there (the solver
+    // kernels only ever see a network that passed; a rejected upload leaves the context empty)
+    int64_t ssum = 0;
+    for (int32_t v = 0; v < n; ++v) ssum += supply[v];
+    if (ssum != 0) return fail(c, PSN_EINFEASIBLE, "supplies do not sum to zero");
+    int rc = setup_rows(c, n, m2, row_off);
+    if (rc != PSN_OK) return rc;
+    const double tu3 = now_up();
+    DevGraph &g = c->g;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_head, head, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_cost, cost, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(d_rev, rev, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_rev, rev, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_ocap, cap, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(g.cap, cap, sizeof(int) * (size_t)m2, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_supply, supply, sizeof(i64) * (size_t)n, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemsetAsync(g.price, 0, sizeof(i64) * (size_t)n, s));
     // arc checks (the far end of every pair is a random read: 46 ms for 10 M arcs on the host, well under 1 ms here)
     unsigned long long *d_chk = reinterpret_cast<unsigned long long *>(c->d_scalar), h_chk[2] = {~0ull, 0};
     HIPCHK(c, hipMemcpyAsync(d_chk, h_chk, sizeof(h_chk), hipMemcpyHostToDevice, s));
-    if (m2 > 0) {
-        hipLaunchKernelGGL(k_fill_tail, dim3(kGrid), dim3(kBlock), 0, s, d_row, (int)n, (unsigned)m2, d_tail);
-        hipLaunchKernelGGL(k_check_arcs, dim3(kGrid), dim3(kBlock), 0, s, (int)n, (unsigned)m2, d_head, g.cap, c->d_cost, d_rev, d_tail, d_chk);
-    }
+    if (m2 > 0)
+        hipLaunchKernelGGL(k_check_arcs, dim3(kGrid), dim3(kBlock), 0, s, (int)n, (unsigned)m2, c->d_head, g.cap, c->d_cost, c->d_rev, g.tail, d_chk);
     HIPCHK(c, hipMemcpyAsync(h_chk, d_chk, sizeof(h_chk), hipMemcpyDeviceToHost, s));
     if ((rc = launch_cover(c)) != PSN_OK) { free_graph_buffers(c); return rc; }
-    HIPCHK(c, hipStreamSynchronize(s));  // host staging vectors die at return
+    HIPCHK(c, hipStreamSynchronize(s));
     if (h_chk[0] != ~0ull) {  // name what is wrong with the first unsound arc
         free_graph_buffers(c);
         const int64_t a = (int64_t)h_chk[0];
@@ -573,9 +583,171 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
     scale_for_cover(c, (long long)c->h_flag[2]);
     const double tu4 = now_up();
     if ((rc = build_graph(c)) != PSN_OK) { free_graph_buffers(c); return rc; }
-    if (dbg_up) fprintf(stderr, "psn_upload_csr: checks %.1f free %.1f classify+alloc %.1f copies %.1f graph capture %.1f ms\n", tu1 - tu0, tu2 - tu1, tu3 - tu2, tu4 - tu3, now_up() - tu4);
+    if (dbg_up) fprintf(stderr, "psn_upload_csr: checks + rows %.1f copies + arc checks %.1f graph capture %.1f ms\n", tu3 - tu0, tu4 - tu3, now_up() - tu4);
     c->uploaded = true;
     return PSN_OK;
+}
+
+// ---- the scheduling network built on the device
+// The residual CSR of a scheduling network is a function of its layout and of a few words per task.
+// The host works out the row offsets and each task's place in its class row and job row; the arcs,
+// five arrays of them, are written where they are used instead of being assembled on the host and
+// copied: 300 MB less over PCIe at 10 000 machines.  Rows may have head-room (reverse places that no
+// task uses yet, task slots that are free): those arcs are placeholders, self-loops paired with
+// themselves.
+__global__ void k_build_placeholders(DevGraph g, int *mhead, int *mcost, int *mrev, int *mocap) {
+    for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) {
+        mhead[a] = g.tail[a]; mrev[a] = (int)a; mcost[a] = 0; mocap[a] = 0; g.cap[a] = 0;
+    }
+}
+__global__ void k_build_task_arcs(DevGraph g, long long count, int v_ec, int v_un, int v_t, int unsched_cost, const int *task_slot,
+                                  const int *task_class, const int *task_job, const int *pos_class, const int *pos_job, int *mhead, int *mcost,
+                                  int *mrev, int *mocap, i64 *supply) {
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock) {
+        const int e = task_class[i], j = task_job[i], vt = v_t + task_slot[i];
+        const unsigned ta = g.row[vt], re = g.row[v_ec + e] + (unsigned)pos_class[i], rj = g.row[v_un + j] + (unsigned)pos_job[i];
+        mhead[ta] = v_ec + e; mocap[ta] = 1; g.cap[ta] = 1; mcost[ta] = 0; mrev[ta] = (int)re;
+        mhead[re] = vt; mocap[re] = 0; g.cap[re] = 0; mcost[re] = 0; mrev[re] = (int)ta;
+        mhead[ta + 1] = v_un + j; mocap[ta + 1] = 1; g.cap[ta + 1] = 1; mcost[ta + 1] = unsched_cost; mrev[ta + 1] = (int)rj;
+        mhead[rj] = vt; mocap[rj] = 0; g.cap[rj] = 0; mcost[rj] = -unsched_cost; mrev[rj] = (int)(ta + 1);
+        supply[vt] = 1;
+    }
+}
+__global__ void k_build_slot_arcs(DevGraph g, int N, int E, int K, int v_ec, const i64 *ec_arc_base, int *mhead, int *mcost, int *mrev, int *mocap) {
+    const long long total = (long long)E * N * K;
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < 2 * total; i += (long long)gridDim.x * kBlock) {
+        const bool fwd = i < total;
+        const long long x = fwd ? i : i - total;
+        // forward threads run machine-major, slot-minor inside a class; reverse threads class-major, slot-minor inside a machine
+        int e, m, k;
+        if (fwd) { e = (int)(x / ((long long)N * K)); const long long r = x - (long long)e * N * K; m = (int)(r / K); k = (int)(r % K); }
+        else { m = (int)(x / ((long long)E * K)); const long long r = x - (long long)m * E * K; e = (int)(r / K); k = (int)(r % K); }
+        const unsigned a = (unsigned)(ec_arc_base[e] + (i64)m * K + k), r = g.row[1 + m] + (unsigned)e * (unsigned)K + (unsigned)k;
+        if (fwd) { mhead[a] = 1 + m; mocap[a] = 0; g.cap[a] = 0; mcost[a] = 0; mrev[a] = (int)r; }
+        else { mhead[r] = v_ec + e; mocap[r] = 0; g.cap[r] = 0; mcost[r] = 0; mrev[r] = (int)a; }
+    }
+}
+__global__ void k_build_sink_arcs(DevGraph g, int N, int E, int J, int K, int v_un, const int *room_job, const int *machine_sink_cap,
+                                  const int *job_sink_cap, int *mhead, int *mcost, int *mrev, int *mocap) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N + J; i += gridDim.x * kBlock) {
+        const bool machine = i < N;
+        const int v = machine ? 1 + i : v_un + (i - N);
+        const unsigned a = machine ? g.row[v] + (unsigned)E * (unsigned)K : g.row[v] + (unsigned)room_job[i - N];
+        const unsigned r = g.row[0] + (unsigned)i;
+        const int cp = machine ? machine_sink_cap[i] : job_sink_cap[i - N];
+        mhead[a] = 0; mocap[a] = cp; g.cap[a] = cp; mcost[a] = 0; mrev[a] = (int)r;
+        mhead[r] = v; mocap[r] = 0; g.cap[r] = 0; mcost[r] = 0; mrev[r] = (int)a;
+    }
+}
+
+int psn_build_network_rooms_device(psn_ctx *c, const psn_layout *lay, int32_t unsched_cost, const int32_t *room_class,
+                                   const int32_t *room_job, const int32_t *machine_sink_cap, const int32_t *job_sink_cap, int64_t n_attached,
+                                   const int32_t *task_slot, const int32_t *task_class, const int32_t *task_job, const int32_t *place_class,
+                                   const int32_t *place_job, int64_t *ec_arc_base_out) {
+    if (!c || !lay || !room_class || !room_job || !machine_sink_cap || !job_sink_cap || unsched_cost < 0 || n_attached < 0 ||
+        (n_attached > 0 && (!task_slot || !task_class || !task_job || !place_class || !place_job)))
+        return fail(c, PSN_EINVAL, "null or out-of-range argument");
+    const int64_t N = lay->n_machines, E = lay->n_classes, J = lay->n_jobs, P = lay->n_tasks, K = lay->k_slots;
+    if (N <= 0 || E <= 0 || J <= 0 || P <= 0 || K <= 0 || n_attached > P) return fail(c, PSN_EINVAL, "bad layout");
+    const int64_t nn = 1 + N + E + J + P;
+    if (nn > INT32_MAX) return fail(c, PSN_EOVERFLOW, "network too large");
+    {   // price magnitudes stay below ~ 8 * n * max|cost| * (n+1); slot costs never exceed 2000 + rounding
+        const long double bound = 8.0L * (long double)nn * (long double)(std::max<int64_t>(unsched_cost, 4096) + 1) * (long double)(nn + 1);
+        if (bound > 4.0e18L) return fail(c, PSN_EOVERFLOW, "n^2 * max|cost| too large for int64 prices");
+    }
+    const int32_t n = (int32_t)nn;
+    const int64_t v_ec = 1 + N, v_un = 1 + N + E, v_t = 1 + N + E + J;
+    std::vector<int64_t> row_off((size_t)n + 1);
+    row_off[0] = 0;
+    row_off[1] = N + J;
+    for (int64_t mm = 0; mm < N; ++mm) {
+        if (machine_sink_cap[mm] < 0) return fail(c, PSN_EINVAL, "negative capacity");
+        row_off[(size_t)(1 + mm + 1)] = row_off[(size_t)(1 + mm)] + E * K + 1;
+    }
+    for (int64_t e = 0; e < E; ++e) {
+        if (room_class[e] < 0) return fail(c, PSN_EINVAL, "negative room");
+        row_off[(size_t)(v_ec + e + 1)] = row_off[(size_t)(v_ec + e)] + room_class[e] + N * K;
+    }
+    for (int64_t j = 0; j < J; ++j) {
+        if (room_job[j] < 0 || job_sink_cap[j] < 0) return fail(c, PSN_EINVAL, "negative room or capacity");
+        row_off[(size_t)(v_un + j + 1)] = row_off[(size_t)(v_un + j)] + room_job[j] + 1;
+    }
+    for (int64_t t = 0; t < P; ++t) row_off[(size_t)(v_t + t + 1)] = row_off[(size_t)(v_t + t)] + 2;
+    const int64_t m2 = row_off[(size_t)n];
+    if (m2 >= (int64_t)0x7FFFFFF0) return fail(c, PSN_EOVERFLOW, "network too large");
+    // every task takes a slot and a place of its own; places lie inside the rooms
+    {
+        std::vector<char> slot_taken((size_t)P, 0);
+        std::vector<std::vector<char>> seen_e((size_t)E), seen_j((size_t)J);
+        for (int64_t i = 0; i < n_attached; ++i) {
+            const int32_t sl = task_slot[i], e = task_class[i], j = task_job[i];
+            if (sl < 0 || sl >= P || e < 0 || e >= E || j < 0 || j >= J || place_class[i] < 0 || place_class[i] >= room_class[e] ||
+                place_job[i] < 0 || place_job[i] >= room_job[j] || slot_taken[(size_t)sl])
+                return fail(c, PSN_EINVAL, "task slot, class, job or place out of range or taken twice");
+            slot_taken[(size_t)sl] = 1;
+            auto &se = seen_e[(size_t)e]; if (se.empty()) se.assign((size_t)room_class[e], 0);
+            auto &sj = seen_j[(size_t)j]; if (sj.empty()) sj.assign((size_t)room_job[j], 0);
+            if (se[(size_t)place_class[i]] || sj[(size_t)place_job[i]]) return fail(c, PSN_EINVAL, "a place in a class or job row is taken twice");
+            se[(size_t)place_class[i]] = 1; sj[(size_t)place_job[i]] = 1;
+        }
+    }
+    std::vector<int64_t> base((size_t)E);
+    for (int64_t e = 0; e < E; ++e) base[(size_t)e] = row_off[(size_t)(v_ec + e)] + room_class[e];
+    int rc = setup_rows(c, n, m2, row_off.data());
+    if (rc != PSN_OK) return rc;
+    // staging: class arc bases; job rooms, sink capacities; the five task tables
+    const size_t A = (size_t)n_attached;
+    const size_t stage_bytes = sizeof(i64) * (size_t)E + sizeof(int) * (5 * A + 2 * (size_t)J + (size_t)N) + 16;
+    char *d;
+    if ((rc = stage(c, stage_bytes, &d)) != PSN_OK) { free_graph_buffers(c); return rc; }
+    i64 *d_base = reinterpret_cast<i64 *>(d);
+    int *d_roomj = reinterpret_cast<int *>(d_base + E), *d_msink = d_roomj + J, *d_jsink = d_msink + N;
+    int *d_slot = d_jsink + J, *d_class = d_slot + A, *d_job = d_class + A, *d_pe = d_job + A, *d_pj = d_pe + A;
+    hipStream_t s = c->stream;
+    DevGraph &g = c->g;
+    hipError_t e = hipMemcpyAsync(d_base, base.data(), sizeof(i64) * (size_t)E, hipMemcpyHostToDevice, s);
+    auto up = [&](int *dst, const int32_t *src, size_t cnt) { if (e == hipSuccess && cnt) e = hipMemcpyAsync(dst, src, sizeof(int) * cnt, hipMemcpyHostToDevice, s); };
+    up(d_roomj, room_job, (size_t)J); up(d_msink, machine_sink_cap, (size_t)N); up(d_jsink, job_sink_cap, (size_t)J);
+    up(d_slot, task_slot, A); up(d_class, task_class, A); up(d_job, task_job, A); up(d_pe, place_class, A); up(d_pj, place_job, A);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_supply, 0, sizeof(i64) * (size_t)n, s);
+    const i64 sink = -(i64)n_attached;
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_supply, &sink, sizeof(i64), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_build_placeholders, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_head, c->d_cost, c->d_rev, c->d_ocap);
+        if (A) hipLaunchKernelGGL(k_build_task_arcs, dim3((unsigned)std::min<int64_t>(kGrid, ((int64_t)A + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, g, (long long)A,
+                                  (int)v_ec, (int)v_un, (int)v_t, (int)unsched_cost, d_slot, d_class, d_job, d_pe, d_pj, c->d_head, c->d_cost, c->d_rev,
+                                  c->d_ocap, c->d_supply);
+        hipLaunchKernelGGL(k_build_slot_arcs, dim3(4096), dim3(kBlock), 0, s, g, (int)N, (int)E, (int)K, (int)v_ec, d_base, c->d_head, c->d_cost,
+                           c->d_rev, c->d_ocap);
+        hipLaunchKernelGGL(k_build_sink_arcs, dim3((unsigned)std::min<int64_t>(kGrid, (N + J + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, g, (int)N, (int)E,
+                           (int)J, (int)K, (int)v_un, d_roomj, d_msink, d_jsink, c->d_head, c->d_cost, c->d_rev, c->d_ocap);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && launch_cover(c) != PSN_OK) e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // the host staging vectors die at return
+    if (e != hipSuccess) { free_graph_buffers(c); return fail(c, PSN_EDEVICE, "psn_build_network_rooms_device", e); }
+    scale_for_cover(c, (long long)c->h_flag[2]);
+    if ((rc = build_graph(c)) != PSN_OK) { free_graph_buffers(c); return rc; }
+    if (ec_arc_base_out) std::copy(base.begin(), base.end(), ec_arc_base_out);
+    c->uploaded = true;
+    return PSN_OK;
+}
+
+int psn_build_network_device(psn_ctx *c, const psn_layout *lay, int32_t slots, int32_t unsched_cost, const int32_t *task_class,
+                             const int32_t *task_job, int64_t *ec_arc_base_out) {
+    if (!c || !lay || !task_class || !task_job || slots < 0 || unsched_cost < 0) return fail(c, PSN_EINVAL, "null or out-of-range argument");
+    const int64_t N = lay->n_machines, E = lay->n_classes, J = lay->n_jobs, P = lay->n_tasks, K = lay->k_slots;
+    if (N <= 0 || E <= 0 || J <= 0 || P <= 0 || K <= 0) return fail(c, PSN_EINVAL, "bad layout");
+    // the exact layout: rooms as large as the membership, tasks in arrival order
+    std::vector<int32_t> cnt_e((size_t)E, 0), cnt_j((size_t)J, 0), slot((size_t)P), pe((size_t)P), pj((size_t)P), msink((size_t)N, slots);
+    for (int64_t t = 0; t < P; ++t) {
+        if (task_class[t] < 0 || task_class[t] >= E || task_job[t] < 0 || task_job[t] >= J) return fail(c, PSN_EINVAL, "task class or job out of range");
+        slot[(size_t)t] = (int32_t)t;
+        pe[(size_t)t] = cnt_e[(size_t)task_class[t]]++;
+        pj[(size_t)t] = cnt_j[(size_t)task_job[t]]++;
+    }
+    return psn_build_network_rooms_device(c, lay, unsched_cost, cnt_e.data(), cnt_j.data(), msink.data(), cnt_j.data(), P, slot.data(), task_class,
+                                          task_job, pe.data(), pj.data(), ec_arc_base_out);
 }
 
 static int eval_costs_impl(psn_ctx *c, const psn_layout *lay, const int64_t *cap_cpu, const int64_t *cap_mem, const int64_t *used_cpu,
@@ -1315,6 +1487,28 @@ int psn_price_scale(psn_ctx *c, int64_t *scale) {
     if (!c || !scale) return fail(c, PSN_EINVAL, "null argument");
     if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
     *scale = c->g.scale;
+    return PSN_OK;
+}
+
+int psn_get_structure(psn_ctx *c, int32_t *head, int32_t *rev) {
+    if (!c || (!head && !rev)) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (head) HIPCHK(c, hipMemcpyAsync(head, c->d_head, (size_t)c->m2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (rev) HIPCHK(c, hipMemcpyAsync(rev, c->d_rev, (size_t)c->m2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSN_OK;
+}
+
+int psn_get_rows(psn_ctx *c, int64_t *row_off, int64_t *supply) {
+    if (!c || (!row_off && !supply)) return fail(c, PSN_EINVAL, "null argument");
+    if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
+    if (row_off) for (size_t v = 0; v < c->h_row.size(); ++v) row_off[v] = c->h_row[v];
+    if (supply) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipMemcpyAsync(supply, c->d_supply, (size_t)c->n * sizeof(i64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return PSN_OK;
 }
 

@@ -115,10 +115,14 @@ struct psn_svc {
     int32_t n = 0;
     i64 m2 = 0;
     int v_ec = 0, v_un = 0, v_t = 0;
+    // The network is kept as what determines it (row offsets, rooms, which task sits where); the arc
+    // arrays themselves exist on the device, and on the host only when somebody asks for them
+    // (materialize).  Arcs rewired since the device copy was last in sync are kept by value.
     std::vector<i64> row_off, supply, ec_arc_base;
-    std::vector<int32_t> head, cap, cost, rev;
+    std::vector<int32_t> room_e, room_j;
+    struct ArcValue { int32_t head, cap, cost; i64 rev; };
     // changes since the device copy was last in sync
-    std::unordered_set<i64> dirty_arcs;
+    std::unordered_map<i64, ArcValue> dirty_arcs;
     std::unordered_map<i64, int32_t> cap_updates;
     std::unordered_set<int32_t> dirty_supply;
     std::vector<int32_t> new_sources;
@@ -140,13 +144,13 @@ struct psn_svc {
 
     // ---------------------------------------------------------------- mirror edits
     void set_arc(i64 a, int h, int cp, int cs, i64 r) {
-        head[(size_t)a] = h; cap[(size_t)a] = cp; cost[(size_t)a] = cs; rev[(size_t)a] = (int32_t)r;
-        if (resident) dirty_arcs.insert(a);
+        if (resident) dirty_arcs[a] = ArcValue{h, cp, cs, r};
     }
     void park(i64 a, int own_vertex) { set_arc(a, own_vertex, 0, 0, a); }
     void set_cap(i64 a, int cp) {
-        cap[(size_t)a] = cp;
-        if (resident && !dirty_arcs.count(a)) cap_updates[a] = cp;
+        if (!resident) return;
+        auto it = dirty_arcs.find(a);
+        if (it != dirty_arcs.end()) it->second.cap = cp; else cap_updates[a] = cp;
     }
     void set_supply(int v, i64 s) {
         supply[(size_t)v] = s;
@@ -396,7 +400,7 @@ struct psn_svc {
         row_off.assign((size_t)n + 1, 0);
         row_off[1] = (i64)N + J;
         for (int m = 0; m < N; ++m) row_off[(size_t)(1 + m + 1)] = row_off[(size_t)(1 + m)] + (i64)E * K + 1;
-        std::vector<int> room_e((size_t)E), room_j((size_t)J);
+        room_e.assign((size_t)E, 0); room_j.assign((size_t)J, 0);
         for (int e = 0; e < E; ++e) {
             room_e[(size_t)e] = (int)(cnt_e[(size_t)e] + std::max<i64>(64, cnt_e[(size_t)e] / 4));
             row_off[(size_t)(v_ec + e + 1)] = row_off[(size_t)(v_ec + e)] + room_e[(size_t)e] + (i64)N * K;
@@ -408,57 +412,23 @@ struct psn_svc {
         for (int t = 0; t < P; ++t) row_off[(size_t)(v_t + t + 1)] = row_off[(size_t)(v_t + t)] + 2;
         m2 = row_off[(size_t)n];
         if (m2 >= (i64)0x7FFFFFF0) return fail(PSN_EOVERFLOW, "too many arcs");
-        head.assign((size_t)m2, 0); cap.assign((size_t)m2, 0); cost.assign((size_t)m2, 0); rev.assign((size_t)m2, 0);
         supply.assign((size_t)n, 0);
         ec_arc_base.assign((size_t)E, 0);
-        resident = false;  // edits below go to the mirror only
+        resident = false;  // the device copy is built from this state at the next round
         dirty_arcs.clear(); cap_updates.clear(); dirty_supply.clear(); new_sources.clear();
         laid_out = true;
         attached = 0;
-        auto pair_up = [&](i64 a, i64 r, int to, int from, int cp, int cs) {
-            head[(size_t)a] = to; cap[(size_t)a] = cp; cost[(size_t)a] = cs; rev[(size_t)a] = (int32_t)r;
-            head[(size_t)r] = from; cap[(size_t)r] = 0; cost[(size_t)r] = -cs; rev[(size_t)r] = (int32_t)a;
-        };
-        // the class x machine x slot block is most of the network; classes write disjoint arcs, so
-        // a large block is filled by a few threads
-        auto fill_classes = [&](int e0, int e1) {
-            for (int e = e0; e < e1; ++e) {
-                const i64 r0 = row_off[(size_t)(v_ec + e)];
-                for (int i = 0; i < room_e[(size_t)e]; ++i) { head[(size_t)(r0 + i)] = v_ec + e; rev[(size_t)(r0 + i)] = (int32_t)(r0 + i); }
-                const i64 base = r0 + room_e[(size_t)e];
-                ec_arc_base[(size_t)e] = base;
-                for (i64 m = 0; m < N; ++m)
-                    for (i64 k = 0; k < K; ++k) pair_up(base + m * K + k, row_off[(size_t)(1 + m)] + (i64)e * K + k, (int)(1 + m), v_ec + e, 0, 0);
-            }
-        };
-        {
-            const int nthreads = (i64)E * N * K >= (1 << 20) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
-            std::vector<std::thread> pool;
-            for (int t = 1; t < nthreads; ++t) pool.emplace_back(fill_classes, (int)((i64)E * t / nthreads), (int)((i64)E * (t + 1) / nthreads));
-            fill_classes(0, E / nthreads);
-            for (auto &th : pool) th.join();
-        }
-        for (int e = 0; e < E; ++e)
+        for (int e = 0; e < E; ++e) {
+            ec_arc_base[(size_t)e] = row_off[(size_t)(v_ec + e)] + room_e[(size_t)e];
             if ((size_t)e < classes.size()) classes[(size_t)e].pool = spare_class_pool(e);
-        for (int j = 0; j < J; ++j) {
-            const i64 r0 = row_off[(size_t)(v_un + j)];
-            for (int i = 0; i < room_j[(size_t)j]; ++i) { head[(size_t)(r0 + i)] = v_un + j; rev[(size_t)(r0 + i)] = (int32_t)(r0 + i); }
-            pair_up(r0 + room_j[(size_t)j], row_off[0] + N + j, 0, v_un + j, 0, 0);
+        }
+        for (int j = 0; j < J; ++j)
             if ((size_t)j < jobs.size()) jobs[(size_t)j].pool = spare_job_pool(j);
-        }
-        for (int m = 0; m < N; ++m) {
-            pair_up(row_off[(size_t)(1 + m)] + (i64)E * K, row_off[0] + m, 0, 1 + m, sink_capacity(m), 0);
-        }
         slot_uid.assign((size_t)P, 0);
         slot_used.assign((size_t)P, 0);
         slot_task.assign((size_t)P, nullptr);
         free_slots.clear();
-        for (int t = P - 1; t >= 0; --t) {
-            free_slots.push_back(t);
-            const i64 ta = row_off[(size_t)(v_t + t)];
-            head[(size_t)ta] = v_t + t; rev[(size_t)ta] = (int32_t)ta;
-            head[(size_t)(ta + 1)] = v_t + t; rev[(size_t)(ta + 1)] = (int32_t)(ta + 1);
-        }
+        for (int t = P - 1; t >= 0; --t) free_slots.push_back(t);
         // runnable tasks in uid order, so that a layout is a function of the state alone
         std::vector<uint64_t> uids;
         uids.reserve(tasks.size());
@@ -478,6 +448,53 @@ struct psn_svc {
         ++st.rebuilds;
         st.build_ms = now_ms() - t0;
         return PSN_OK;
+    }
+
+    // The arc arrays of the network as psn_upload_csr would take them (slot arcs unpriced), from the
+    // state: placeholders everywhere, then slot arcs, sink arcs and the arcs of the attached tasks.
+    void materialize(std::vector<int32_t> &head, std::vector<int32_t> &cap, std::vector<int32_t> &cost, std::vector<int32_t> &rev) const {
+        head.assign((size_t)m2, 0); cap.assign((size_t)m2, 0); cost.assign((size_t)m2, 0); rev.assign((size_t)m2, 0);
+        for (int v = 0; v < n; ++v)
+            for (i64 a = row_off[(size_t)v]; a < row_off[(size_t)v + 1]; ++a) { head[(size_t)a] = v; rev[(size_t)a] = (int32_t)a; }
+        auto pair_up = [&](i64 a, i64 r, int to, int from, int cp, int cs) {
+            head[(size_t)a] = to; cap[(size_t)a] = cp; cost[(size_t)a] = cs; rev[(size_t)a] = (int32_t)r;
+            head[(size_t)r] = from; cap[(size_t)r] = 0; cost[(size_t)r] = -cs; rev[(size_t)r] = (int32_t)a;
+        };
+        for (int e = 0; e < E; ++e)
+            for (i64 m = 0; m < N; ++m)
+                for (i64 k = 0; k < K; ++k)
+                    pair_up(ec_arc_base[(size_t)e] + m * K + k, row_off[(size_t)(1 + m)] + (i64)e * K + k, (int)(1 + m), v_ec + e, 0, 0);
+        for (int m = 0; m < N; ++m) pair_up(machine_sink_arc(m), row_off[0] + m, 0, 1 + m, sink_capacity(m), 0);
+        for (int j = 0; j < J; ++j)
+            pair_up(row_off[(size_t)(v_un + j)] + room_j[(size_t)j], row_off[0] + N + j, 0, v_un + j,
+                    (size_t)j < jobs.size() && jobs[(size_t)j].used ? jobs[(size_t)j].pool.count : 0, 0);
+        for (int t = 0; t < P; ++t) {
+            if (!slot_used[(size_t)t]) continue;
+            const Task &tk = *slot_task[(size_t)t];
+            const int vt = v_t + t;
+            const i64 ta = row_off[(size_t)vt];
+            pair_up(ta, tk.place_class, v_ec + tk.cls, vt, 1, 0);
+            pair_up(ta + 1, tk.place_job, v_un + tk.job, vt, 1, cfg.unsched_cost);
+        }
+    }
+    // Build the device copy from the state (no arc array crosses PCIe).
+    int build_on_device() {
+        std::vector<int32_t> msink((size_t)N), jsink((size_t)J), slot, cls, job, pe, pj;
+        for (int m = 0; m < N; ++m) msink[(size_t)m] = sink_capacity(m);
+        for (int j = 0; j < J; ++j) jsink[(size_t)j] = (size_t)j < jobs.size() && jobs[(size_t)j].used ? jobs[(size_t)j].pool.count : 0;
+        slot.reserve((size_t)attached); cls.reserve((size_t)attached); job.reserve((size_t)attached); pe.reserve((size_t)attached); pj.reserve((size_t)attached);
+        for (int t = 0; t < P; ++t) {
+            if (!slot_used[(size_t)t]) continue;
+            const Task &tk = *slot_task[(size_t)t];
+            slot.push_back(t); cls.push_back(tk.cls); job.push_back(tk.job);
+            pe.push_back((int32_t)(tk.place_class - row_off[(size_t)(v_ec + tk.cls)]));
+            pj.push_back((int32_t)(tk.place_job - row_off[(size_t)(v_un + tk.job)]));
+        }
+        std::vector<i64> base((size_t)E);
+        const int rc = psn_build_network_rooms_device(ctx, &lay, cfg.unsched_cost, room_e.data(), room_j.data(), msink.data(), jsink.data(),
+                                                      (i64)slot.size(), slot.data(), cls.data(), job.data(), pe.data(), pj.data(), base.data());
+        if (rc == PSN_OK && base != ec_arc_base) return PSN_EINVAL;
+        return rc;
     }
 
     // External usage per machine.  A measured figure covers everything on the machine, the tasks the
@@ -803,7 +820,12 @@ int psn_svc_export_network(psn_svc *s, int64_t *row_off, int32_t *head, int32_t 
     if (!s->laid_out || s->need_layout) { const int rc = s->layout(); if (rc != PSN_OK) return rc; }
     auto put64 = [](int64_t *dst, const std::vector<i64> &v) { if (dst) std::copy(v.begin(), v.end(), dst); };
     auto put32 = [](int32_t *dst, const std::vector<int32_t> &v) { if (dst) std::copy(v.begin(), v.end(), dst); };
-    put64(row_off, s->row_off); put32(head, s->head); put32(cap, s->cap); put32(cost, s->cost); put32(rev, s->rev);
+    put64(row_off, s->row_off);
+    if (head || cap || cost || rev) {
+        std::vector<int32_t> h, c, k, r;
+        s->materialize(h, c, k, r);
+        put32(head, h); put32(cap, c); put32(cost, k); put32(rev, r);
+    }
     put64(supply, s->supply); put64(ec_arc_base, s->ec_arc_base);
     std::vector<i64> cc, cm, uc, um, rc, rm;
     s->cost_inputs(cc, cm, uc, um, rc, rm);
@@ -814,6 +836,8 @@ int psn_svc_export_network(psn_svc *s, int64_t *row_off, int32_t *head, int32_t 
 int64_t psn_svc_schedule(psn_svc *s) {
     if (!s) return PSN_EINVAL;
     if (!s->ctx) return s->fail(PSN_ESTATE, "no device: the service was created with device = -1");
+    const double t_round = now_ms();
+    struct RoundClock { psn_svc *s; double t0; ~RoundClock() { s->st.total_ms = now_ms() - t0; } } round_clock{s, t_round};
     ++s->st.rounds;
     s->st.build_ms = s->st.upload_ms = s->st.update_ms = s->st.solve_ms = s->st.extract_ms = 0;
     s->st.patched_arcs = s->st.cap_updates = s->st.supply_updates = 0;
@@ -845,9 +869,8 @@ int64_t psn_svc_schedule(psn_svc *s) {
     bool warm = false;
     if (!s->resident) {
         double t0 = now_ms();
-        rc = psn_upload_csr(s->ctx, s->n, s->m2, s->row_off.data(), s->head.data(), s->cap.data(), s->cost.data(), s->rev.data(),
-                            s->supply.data());
-        if (rc != PSN_OK) return s->fail(rc, std::string("upload: ") + psn_last_error(s->ctx));
+        rc = s->build_on_device();
+        if (rc != PSN_OK) return s->fail(rc, std::string("build on device: ") + psn_last_error(s->ctx));
         if (s->any_selector) {
             rc = psn_set_admission_mask(s->ctx, &s->lay, s->allow.data());
             if (rc != PSN_OK) return s->fail(rc, std::string("admission mask: ") + psn_last_error(s->ctx));
@@ -862,12 +885,14 @@ int64_t psn_svc_schedule(psn_svc *s) {
     } else {
         double t0 = now_ms();
         if (!s->dirty_arcs.empty()) {
-            std::vector<i64> idx(s->dirty_arcs.begin(), s->dirty_arcs.end());
+            std::vector<i64> idx;
+            idx.reserve(s->dirty_arcs.size());
+            for (auto &kv : s->dirty_arcs) idx.push_back(kv.first);
             std::sort(idx.begin(), idx.end());
             std::vector<int32_t> h(idx.size()), c(idx.size()), k(idx.size()), r(idx.size());
             for (size_t i = 0; i < idx.size(); ++i) {
-                const size_t a = (size_t)idx[i];
-                h[i] = s->head[a]; c[i] = s->cap[a]; k[i] = s->cost[a]; r[i] = s->rev[a];
+                const auto &av = s->dirty_arcs[idx[i]];
+                h[i] = av.head; c[i] = av.cap; k[i] = av.cost; r[i] = (int32_t)av.rev;
             }
             rc = psn_patch_arcs(s->ctx, (i64)idx.size(), idx.data(), h.data(), c.data(), k.data(), r.data());
             if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("patch: ") + psn_last_error(s->ctx)); }
@@ -877,7 +902,7 @@ int64_t psn_svc_schedule(psn_svc *s) {
             std::vector<i64> idx;
             std::vector<int32_t> cp;
             for (auto &kv : s->cap_updates)
-                if (!s->dirty_arcs.count(kv.first)) { idx.push_back(kv.first); cp.push_back(s->cap[(size_t)kv.first]); }
+                if (!s->dirty_arcs.count(kv.first)) { idx.push_back(kv.first); cp.push_back(kv.second); }
             rc = psn_update_caps(s->ctx, (i64)idx.size(), idx.data(), cp.data());
             if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("update_caps: ") + psn_last_error(s->ctx)); }
             s->st.cap_updates = (i64)idx.size();

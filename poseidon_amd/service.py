@@ -33,7 +33,7 @@ class SvcStats(C.Structure):
                 ("build_ms", C.c_double), ("upload_ms", C.c_double), ("update_ms", C.c_double),
                 ("solve_ms", C.c_double), ("extract_ms", C.c_double),
                 ("total_cost", C.c_int64), ("last_round_warm", C.c_int32),
-                ("tasks_running", C.c_int64), ("tasks_deferred", C.c_int64)]
+                ("tasks_running", C.c_int64), ("total_ms", C.c_double), ("tasks_deferred", C.c_int64)]
 
 
 class Selector(C.Structure):  # include/psn_service.h psn_selector

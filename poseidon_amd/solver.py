@@ -89,6 +89,38 @@ class Solver:
         self.upload_csr(net.n, net.row_off, net.head, net.cap, net.cost, net.rev, net.supply)
         self.layout = net.layout
 
+    def build_network(self, cl: Cluster, unsched_cost: int | None = None):
+        """Build the scheduling network of `cl` on the device (psn_build_network_device) and make it
+        the resident network.  Returns a Network that carries the layout and ec_arc_base only (the
+        arc arrays exist on the device; fetch them with costs() / residual() if needed)."""
+        from .network import UNSCHED_COST
+        lay = cl.layout
+        n = 1 + lay.n_machines + lay.n_classes + lay.n_jobs + lay.n_tasks
+        m2 = 2 * (2 * lay.n_tasks + lay.n_classes * lay.n_machines * lay.k_slots + lay.n_machines + lay.n_jobs)
+        base = np.empty(lay.n_classes, np.int64)
+        tc = np.ascontiguousarray(cl.task_class, np.int32)
+        tj = np.ascontiguousarray(cl.task_job, np.int32)
+        self._chk(self._lib.psn_build_network_device(self._ctx, C.byref(lay), int(cl.slots),
+                                                     int(UNSCHED_COST if unsched_cost is None else unsched_cost),
+                                                     _vp(tc), _vp(tj), _vp(base)))
+        self.n, self.m2, self.layout = n, m2, lay
+        empty32 = np.empty(0, np.int32)
+        return Network(lay, n, m2, np.empty(0, np.int64), empty32, empty32, empty32, empty32, np.empty(0, np.int64), base)
+
+    def structure(self):
+        """(head, rev) of the resident network, read back from the device."""
+        head = np.empty(self.m2, np.int32)
+        rev = np.empty(self.m2, np.int32)
+        self._chk(self._lib.psn_get_structure(self._ctx, _vp(head), _vp(rev)))
+        return head, rev
+
+    def rows(self):
+        """(row_off, supply) of the resident network."""
+        row_off = np.empty(self.n + 1, np.int64)
+        supply = np.empty(self.n, np.int64)
+        self._chk(self._lib.psn_get_rows(self._ctx, _vp(row_off), _vp(supply)))
+        return row_off, supply
+
     def eval_costs(self, cl: Cluster, net: Network):
         self._chk(self._lib.psn_eval_costs(self._ctx, C.byref(cl.layout), _vp(cl.cap_cpu), _vp(cl.cap_mem),
                                            _vp(cl.used_cpu), _vp(cl.used_mem), _vp(cl.req_cpu),

@@ -395,3 +395,35 @@ def test_cost_model_rejects_a_layout_it_cannot_price():
         sv.upload(net)
         sv.eval_costs(cl, net)
         assert sv.solve().total_cost == 587046
+
+
+@pytest.mark.parametrize("cfg,seed", [(0, 1), (1, 2)])
+def test_network_built_on_the_device_equals_the_host_builder(cfg, seed):
+    """psn_build_network_device writes, arc for arc, what psn_build_network lays out (and what the
+    oracle's builder lays out: the arrays' FNV checksum is the committed golden one once priced)."""
+    cl = pa.synth_cluster(cfg, seed)
+    net = pa.build_network(cl)
+    with pa.Solver(device=0) as s:
+        dnet = s.build_network(cl)
+        assert np.array_equal(dnet.ec_arc_base, net.ec_arc_base)
+        head, rev = s.structure()
+        row_off, supply = s.rows()
+        cost, ocap = s.costs()
+        assert np.array_equal(row_off, net.row_off) and np.array_equal(supply, net.supply)
+        assert np.array_equal(head, net.head) and np.array_equal(rev, net.rev)
+        assert np.array_equal(cost, net.cost) and np.array_equal(ocap, net.cap)
+        assert np.array_equal(s.residual(), net.cap)
+        s.eval_costs(cl, dnet)
+        og = synth.build_graph(synth.make_cluster(cfg, seed))
+        cost, ocap = s.costs()
+        assert np.array_equal(cost, og.cost) and np.array_equal(ocap, og.cap)
+        assert capi.fnv1a64(row_off, head, ocap, cost, rev, supply) == int(_gold(cfg, seed)["csr_fnv1a64"], 16)
+        r = s.solve()
+        assert r.total_cost == _gold(cfg, seed)["optimal_cost"]
+        assert capi.check(og, s.residual(), s.prices(), scale=s.price_scale())[:2] == (0, r.total_cost)
+        # malformed task tables are refused before anything is built
+        bad = pa.synth_cluster(cfg, seed)
+        bad.task_class = bad.task_class.copy(); bad.task_class[3] = 64
+        with pytest.raises(pa.PsnError) as ei:
+            s.build_network(bad)
+        assert ei.value.code == _lib.PSN_EINVAL
