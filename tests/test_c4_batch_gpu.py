@@ -88,3 +88,45 @@ def test_group_of_two_is_not_slower_path_but_same_answer():
     assert all(r.launches > 0 for r in res)
     for s in solvers:
         s.close()
+
+
+def test_gather_placements_through_the_c_abi():
+    """psn_solve_batch + psn_gather_placements: the whole batch of what-if rounds from one process,
+    contexts spread over as many GPUs as the node shows (all on one when there is one), rows gathered
+    into host memory and into memory of GPU 0; every row equals the context's own placements."""
+    import ctypes as C
+
+    import torch
+
+    from poseidon_amd import _lib
+    lib = pa.load_library()
+    ndev = torch.cuda.device_count()
+    B = 6
+    solvers, clusters = [], []
+    for b in range(B):
+        cl = pa.synth_cluster(0, 30 + b, 40 + 4 * b, 300 + 50 * b)
+        s = pa.Solver(device=b % ndev)
+        net = s.build_network(cl)
+        s.eval_costs(cl, net)
+        solvers.append(s); clusters.append(cl)
+    res = batch.solve_batch(solvers)
+    for r, cl, b in zip(res, clusters, range(B)):
+        rc, tc, _, _, _ = capi.cost_scaling(synth.build_graph(synth.make_cluster(0, 30 + b, 40 + 4 * b, 300 + 50 * b)))
+        assert rc == 0 and r.total_cost == tc
+    stride = max(cl.layout.n_tasks for cl in clusters)
+    ctxs = (C.c_void_p * B)(*[s._ctx for s in solvers])
+    lays = (_lib.Layout * B)(*[cl.layout for cl in clusters])
+    host = np.full((B, stride), -9, np.int32)
+    assert lib.psn_gather_placements(ctxs, B, lays, stride, -1, host.ctypes.data) == _lib.PSN_OK
+    dev = torch.full((B, stride), -9, dtype=torch.int32, device="cuda:0")
+    assert lib.psn_gather_placements(ctxs, B, lays, stride, 0, C.c_void_p(dev.data_ptr())) == _lib.PSN_OK
+    torch.cuda.synchronize()
+    for b, (s, cl) in enumerate(zip(solvers, clusters)):
+        want = s.placements()
+        P = cl.layout.n_tasks
+        assert np.array_equal(host[b, :P], want) and (host[b, P:] == -9).all()
+        assert np.array_equal(dev[b, :P].cpu().numpy(), want)
+    # a stride shorter than a row is refused
+    assert lib.psn_gather_placements(ctxs, B, lays, 10, -1, host.ctypes.data) == _lib.PSN_EINVAL
+    for s in solvers:
+        s.close()
