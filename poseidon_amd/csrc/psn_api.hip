@@ -337,9 +337,6 @@ __global__ void k_sum_supply(const i64 *supply, int n, i64 *out) {
 
 constexpr int kScalarSlots = 40;
 constexpr int kSupplySumSlot = 38;  // d_scalar: [0] total cost, [1] max violation, [2..35] cost statistics, [38] supply sum
-#ifdef PSN_STAMPS
-constexpr size_t kStampWords = (size_t)65536 + (size_t)8 * 64 * 4096 * 2 + (size_t)8 * 64 * 2;
-#endif
 
 // Marks and counts the vertex cover of the resident network on the context's stream; the count is
 // on its way to h_flag[2] when this returns (d_scalar slot kCoverSlot is the device counter).
@@ -507,10 +504,6 @@ static int setup_rows(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off)
     A(g.dmax_part, (size_t)kGrid * (kBlock / 64))
     A(g.tally, (size_t)c->tally_slots * kTallyN) A(c->d_tally_out, kTallyN) A(g.ctrl, 1)
     if (std::getenv("PSN_TRACE")) { A(g.dbg, kDbgCap) A(g.dbg_cnt, 1) }
-#ifdef PSN_STAMPS
-    A(g.stamps, kStampWords)
-    HIPCHK(c, hipMemset(g.stamps, 0, kStampWords * sizeof(unsigned long long)));
-#endif
 #undef A
     c->d_head = d_head; c->d_rev = d_rev;
     g.row = d_row; g.head = d_head; g.cost = c->d_cost; g.rev = d_rev; g.tail = d_tail; g.ocap = c->d_ocap; g.cls = d_cls;
@@ -1590,18 +1583,6 @@ int psn_debug_trace(psn_ctx *c, int32_t *out4, int64_t max_records, int64_t *cou
     return PSN_OK;
 }
 
-#ifdef PSN_STAMPS
-int psn_debug_stamps(psn_ctx *c, unsigned long long *out) {  // kGrid * 4 waves * 16 values
-    if (!c || !out || !c->g.stamps) return PSN_EINVAL;
-    HIPCHK(c, hipMemcpy(out, c->g.stamps, (size_t)kGrid * (kBlock / 64) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return PSN_OK;
-}
-int psn_debug_spans(psn_ctx *c, unsigned long long *out) {  // kStampWords - 65536 values
-    if (!c || !out || !c->g.stamps) return PSN_EINVAL;
-    HIPCHK(c, hipMemcpy(out, c->g.stamps + 65536, (kStampWords - 65536) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return PSN_OK;
-}
-#endif
 
 int psn_kernel_times(psn_ctx *c, double *ms, uint64_t *calls) {
     if (!c || !ms || !calls) return fail(c, PSN_EINVAL, "null argument");

@@ -69,7 +69,6 @@ struct DevGraph {
     i64 *seg_scan, *seg_add[2];
     int n_hub_segs;
     i64 *dmax_part;  // largest distance handed out, one slot per wave of the largest sweep grid
-    unsigned long long *stamps;  // diagnostic builds (PSN_STAMPS) only, else null
     int *cap, *rcap;
     i64 *price, *excess, *cand, *dist;
     int2 *list_low[2];  // active vertices of degree <= kLowMax (one lane each)

@@ -70,74 +70,10 @@ __device__ __forceinline__ unsigned mix32(unsigned a, unsigned b) {
     return (unsigned)z;
 }
 
-// Per-wave work counters; folded into a per-wave slot (no atomics: wave w of block b owns
-// slot (b, w) in every launch, and launches on one stream are ordered).  A wave that
-// counted nothing skips the fold.
-#ifdef PSN_STAMPS
-// Diagnostic build only: cycle stamps per wave of the global-update sweep (tools/stamps_report.py).
-__device__ __forceinline__ unsigned long long stamp_now() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-// Per launch and wave: begin and end on the 100 MHz clock, for replays kSpanEpoch0 .. +8 only
-// (plain stores into the wave's own slots; the host takes min / max):
-// stamps[65536 + (((epoch - kSpanEpoch0) * 64 + slot) * 4096 + wave) * 2 ...]; work sizes at the
-// end of the buffer.
-constexpr unsigned kSpanEpoch0 = 40, kSpanEpochs = 8;
-#ifndef PSN_STAMP_EXPAND_MIN
-#define PSN_STAMP_EXPAND_MIN 9000u  // per-wave records of the expand sweep; above any frontier: the push sweep records instead
-#endif
-constexpr unsigned kStampExpandMin = PSN_STAMP_EXPAND_MIN;
-#ifndef PSN_STAMP_EXPAND_MAX
-#define PSN_STAMP_EXPAND_MAX 4000000000u
-#endif
-constexpr unsigned kStampExpandMax = PSN_STAMP_EXPAND_MAX;
-#ifndef PSN_STAMP_PUSH_MIN
-#define PSN_STAMP_PUSH_MIN 200u  // wave-item counts of the push sweeps that leave per-wave records
-#endif
-#ifndef PSN_STAMP_PUSH_MAX
-#define PSN_STAMP_PUSH_MAX 3000u
-#endif
-#ifndef PSN_STAMP_PUSH
-#define PSN_STAMP_PUSH 1  // 0: the push sweep leaves the per-wave records to the expand sweep
-#endif
-__device__ __forceinline__ unsigned long long *span_slot(const DevGraph &g, unsigned slot) {
-    const unsigned ep = g.ctrl->epoch - kSpanEpoch0;
-    if (!g.stamps || ep >= kSpanEpochs || lane_id() != 0) return nullptr;
-    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    return g.stamps + 65536 + (((size_t)ep * 64 + slot) * 4096 + wave) * 2;
-}
-__device__ __forceinline__ void span_begin(const DevGraph &g, unsigned slot, unsigned long long a, unsigned long long b) {
-    unsigned long long *o = span_slot(g, slot);
-    if (!o) return;
-    o[0] = __builtin_amdgcn_s_memrealtime();
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long *w = g.stamps + 65536 + (size_t)kSpanEpochs * 64 * 4096 * 2 + ((size_t)(g.ctrl->epoch - kSpanEpoch0) * 64 + slot) * 2;
-        w[0] = a; w[1] = b;
-    }
-}
-__device__ __forceinline__ void span_end(const DevGraph &g, unsigned slot) {
-    unsigned long long *o = span_slot(g, slot);
-    if (!o) return;
-    __builtin_amdgcn_s_waitcnt(0);
-    o[1] = __builtin_amdgcn_s_memrealtime();
-}
-#define SPAN_BEGIN(slot, a, b) span_begin(g, slot, a, b)
-#define SPAN_END(slot) span_end(g, slot)
-#define STAMP(var) const unsigned long long var = stamp_now()
-#define STAMP_ADD(acc, a, b) acc += (b) - (a)
-#else
-#define STAMP(var)
-#define STAMP_ADD(acc, a, b)
-#define SPAN_BEGIN(slot, a, b)
-#define SPAN_END(slot)
-#endif
-
 // Per-wave work counters: 32-bit while a sweep runs (one wave scans far fewer than 2^32 arcs in
-// one launch), added to the wave's 64-bit slot in memory when it ends.
+// one launch), added to the wave's 64-bit slot in memory when it ends (no atomics: wave w of block
+// b owns slot (b, w) in every launch, and launches on one stream are ordered).  A wave that
+// counted nothing skips the fold.
 struct Tally { unsigned c[kTallyN]; __device__ Tally() { for (int i = 0; i < kTallyN; ++i) c[i] = 0; } };
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned x) {
 #pragma unroll
@@ -199,9 +135,6 @@ struct AppendLds {
     int v[kSplitCap];
     unsigned r0[kSplitCap], r1[kSplitCap], rot[kSplitCap], pref[kSplitCap + 1];
     unsigned n, nsegs;
-#ifdef PSN_PROBE_APPEND
-    unsigned long long *probe;
-#endif
 };
 // Items written here carry no bound slots: the relabel sweep handles the hubs, whose segments
 // do, outside this helper (one workgroup per hub).
@@ -212,9 +145,6 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
     // extra_segs (workgroup-uniform): further wave-item slots the caller fills itself, taken with
     // the same atomic; *extra_base receives the first of them.
     unsigned nl = 0, ns = 0;
-#ifdef PSN_PROBE_APPEND
-    const unsigned long long q0 = stamp_now();
-#endif
 #pragma unroll
     for (int i = 0; i < VPT; ++i) { nl += take[i] && cls[i] == kClsLow; ns += take[i] && cls[i] == kClsMed; }
     const unsigned il = wave_incl_scan_u32(nl), is = wave_incl_scan_u32(ns);
@@ -222,9 +152,6 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
     if (lane_id() == 63) { lds.sums[0][w] = il; lds.sums[1][w] = is; }
     if (threadIdx.x == 0) { lds.n = 0; lds.nsegs = 0; }
     __syncthreads();
-#ifdef PSN_PROBE_APPEND
-    const unsigned long long q1 = stamp_now();
-#endif
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {  // stage the split vertices
         if (take[i] && cls[i] == kClsHigh) {
@@ -239,9 +166,6 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
         }
     }
     __syncthreads();
-#ifdef PSN_PROBE_APPEND
-    const unsigned long long q2 = stamp_now();
-#endif
     // One atomic per list takes the slots of the whole workgroup: lane items; wave items of the
     // unsplit vertices followed by the segments of the staged ones.
     const unsigned nsplit = min(lds.n, (unsigned)kSplitCap), nsplit_segs = lds.nsegs;  // workgroup-uniform
@@ -264,9 +188,6 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
     }
     if (threadIdx.x < 2) lds.sums[threadIdx.x][kBlock / 64] = my_base;
     __syncthreads();
-#ifdef PSN_PROBE_APPEND
-    const unsigned long long q3 = stamp_now();
-#endif
     unsigned pl = lds.sums[0][kBlock / 64] + il - nl, ps = lds.sums[1][kBlock / 64] + is - ns;
     unsigned med_total = 0;
     for (int i = 0; i < kBlock / 64; ++i) med_total += lds.sums[1][i];
@@ -277,9 +198,6 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
         if (cls[i] == kClsLow) lowl[pl++] = low_item(v[i], r0[i], r1[i]);
         else if (cls[i] == kClsMed) segl[ps++] = solo_item(v[i], r0[i], r1[i]);
     }
-#ifdef PSN_PROBE_APPEND
-    const unsigned long long q4 = stamp_now();
-#endif
     if (extra_base) *extra_base = lds.sums[1][kBlock / 64] + med_total + nsplit_segs;
     if (nsplit) {
         // Wave w writes the staged vertices w, w + 4, ...: lane l first fetches the record of the
@@ -306,18 +224,6 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
             }
         }
     }
-#ifdef PSN_PROBE_APPEND
-    {
-        const unsigned long long q5 = stamp_now();
-        __builtin_amdgcn_s_waitcnt(0);
-        const unsigned long long q6 = stamp_now();
-        if (lds.probe && lane_id() == 0 && (nsplit || blockIdx.x == 5) && (unsigned long long)(nsplit + med_total) >= lds.probe[(size_t)(blockIdx.x * (kBlock / 64) + w) * 16 + 9]) {
-            unsigned long long *o = lds.probe + (size_t)(blockIdx.x * (kBlock / 64) + w) * 16;
-            o[9] = nsplit + med_total;
-            o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3; o[4] = q4; o[5] = q5; o[6] = q6; o[7] = nsplit; o[8] = nsplit_segs; o[13] = 4242;
-        }
-    }
-#endif
     __syncthreads();
 }
 
@@ -441,17 +347,8 @@ __device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, in
 // several items has its waves claim what they want to push from excess[u] and hand back
 // what was not granted.  `rot` permutes which lane owns which arcs, so that the prefix
 // order (= who gets the excess first) changes from round to round.
-#ifdef PSN_STAMPS
-struct PushStamps { unsigned long long pre = 0, arcs = 0, price = 0, push = 0, tail = 0, n = 0; };
-#define PS_ARG , PushStamps &ps
-#define PS_PASS , ps
-#else
-#define PS_ARG
-#define PS_PASS
-#endif
-__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int4 it, i64 S, unsigned rot, int par, Tally &t PS_ARG) {
+__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int4 it, i64 S, unsigned rot, int par, Tally &t) {
     const int lane = lane_id();
-    STAMP(tp0);
     const int u = it.x;
     const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
     const bool solo = it.w & 1;
@@ -479,25 +376,13 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
     i64 e = e0, best = kNegInf;
     bool incomplete = false;
     const unsigned plane = (unsigned)(lane + rot) & 63u;
-    STAMP(tp1);
-    STAMP_ADD(ps.pre, tp0, tp1);
-#ifdef PSN_STAMPS
-    ps.n++;
-#endif
     for (unsigned h = r0; h < r1; h += kStep) {
-        STAMP(ta0);
         const unsigned a0 = h + plane * 8, lim8 = min(r1, h + 512), at = h + 512 + plane, limt = min(r1, h + kStep);
         int cp[9], hd[9], cs[9];
         load9(g.cap, a0, lim8, at, limt, cp);
         load9(g.head, a0, lim8, at, limt, hd);
         load9(g.cost, a0, lim8, at, limt, cs);
         t.c[kTallyScans] += count9(a0, lim8, at, limt);
-#ifdef PSN_STAMPS
-#pragma unroll
-        for (int j = 0; j < 9; ++j) asm volatile("" ::"v"(cp[j]), "v"(hd[j]), "v"(cs[j]));
-#endif
-        STAMP(ta1);
-        STAMP_ADD(ps.arcs, ta0, ta1);
         // Keys price[head] - cost * S are not kept per arc: what later steps need is which arcs are
         // admissible (a bit mask), the largest key of all live arcs and the largest key among the
         // live arcs that are not admissible.  If an admissible arc is still residual after the
@@ -519,11 +404,6 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
                 else kmax_rest = key > kmax_rest ? key : kmax_rest;
             }
         }
-#ifdef PSN_STAMPS
-        asm volatile("" ::"v"(want));
-#endif
-        STAMP(ta2);
-        STAMP_ADD(ps.price, ta1, ta2);
         bool stop = false;
         if (__ballot(want > 0)) {
             const i64 incl = wave_incl_scan(want);
@@ -577,8 +457,6 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
                     }
                 }
             }
-            STAMP(ta3);
-            STAMP_ADD(ps.push, ta2, ta3);
             stop = granted < total || (solo && e == 0);  // out of excess
         }
         bool adm_left = false;
@@ -591,7 +469,6 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
             break;
         }
     }
-    STAMP(tq0);
     best = wave_max(best);
     if (lane == 0) {
         if (seg1 && !incomplete) {
@@ -604,8 +481,6 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
         if (best > kNegInf) amax64(&g.cand[u], best);
         if (solo && e != e0) aadd64(&g.excess[u], e - e0);
     }
-    STAMP(tq1);
-    STAMP_ADD(ps.tail, tq0, tq1);
 }
 
 __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
@@ -619,7 +494,6 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
         const unsigned i = aadd32(g.dbg_cnt, 1u);
         if (i < kDbgCap) g.dbg[i] = make_int4(1, k, (int)nlow, (int)nseg);
     }
-    SPAN_BEGIN(16u + 2u * (unsigned)k, nlow, nseg);
     __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
     const HubAcc hb{s_add, s_max};
     hub_init(hb, kNegInf);
@@ -631,38 +505,14 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
     const int my_hub_vertex = hub_vertex_of_thread(g);
-#ifdef PSN_STAMPS
-    PushStamps ps;
-    unsigned long long acc_item = 0;
-#endif
-    STAMP(tk0);
     for (unsigned i = wave; i < nseg; i += nwaves) {
-        STAMP(ti0);
         const int4 it = segl[i];
-#ifdef PSN_STAMPS
-        asm volatile("" ::"v"(it.x), "v"(it.y), "v"(it.z), "v"(it.w));
-#endif
-        STAMP(ti1);
-        STAMP_ADD(acc_item, ti0, ti1);
-        push_item(g, hb, it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t PS_PASS);
+        push_item(g, hb, it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t);
     }
-    STAMP(tk1);
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, hb, lowl[i], S, k & 1, t);
-    STAMP(tk2);
     hub_flush_push(g, hb, my_hub_vertex);
-    STAMP(tk3);
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyRounds]++;
     tally_flush<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds>(g, t);
-#ifdef PSN_STAMPS
-    if (PSN_STAMP_PUSH && g.stamps && nseg >= PSN_STAMP_PUSH_MIN && nseg < PSN_STAMP_PUSH_MAX && (nlow == 0 || PSN_STAMP_PUSH_MIN >= 3000u) && lane_id() == 0) {
-        __builtin_amdgcn_s_waitcnt(0);
-        const unsigned long long tk4 = stamp_now();
-        unsigned long long *o = g.stamps + (size_t)wave * 16;
-        o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = tk4; o[5] = ps.n; o[6] = acc_item; o[7] = ps.pre; o[8] = ps.arcs;
-        o[9] = ps.price; o[10] = ps.push; o[11] = ps.tail; o[12] = nseg; o[13] = 777;
-    }
-#endif
-    SPAN_END(16u + 2u * (unsigned)k);
 }
 
 // Relabel (optional) + rebuild of the active lists for the next round: one sweep over
@@ -701,7 +551,6 @@ __device__ __forceinline__ void append_hub(const HubTurn &h, unsigned slot_base,
 }
 
 __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, int do_relabel) {
-    STAMP(t_entry);
     Ctrl *ct = g.ctrl;
     // The first batch of vertex words is asked for before the control words are known: both
     // arrive in one round trip, and a launch that turns out to be switched off just drops them.
@@ -734,13 +583,9 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
     }
     const i64 eps = ct->eps;
     const unsigned rot = mix32(ct->epoch, (unsigned)k);
-    SPAN_BEGIN(do_relabel ? 17u + 2u * (unsigned)k : 15u, (unsigned long long)do_relabel, stamp_now() - t_entry + 0 * eps + 0 * rot);
     Tally t;
     __shared__ AppendLds s_app;
     __shared__ unsigned s_hub_base;
-#ifdef PSN_PROBE_APPEND
-    if (threadIdx.x == 0) s_app.probe = do_relabel ? g.stamps : nullptr;
-#endif
     HubTurn hub{};
     if (hub0 >= 0) hub = hub_fetch(g, hub0);  // decided below
     int hub_state = hub0 >= 0 ? 1 : 0;  // 1: fetched, 2: dealt with
@@ -776,7 +621,6 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
         __syncthreads();
     }
     tally_flush<kTallyRelabels>(g, t);
-    SPAN_END(do_relabel ? 17u + 2u * (unsigned)k : 15u);
 }
 
 // ------------------------------------------------------------- per-phase saturation
@@ -994,26 +838,12 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     i64 wmax = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyGuIters]++;
     const int4 *segl = g.fr_seg[src];
-#ifdef PSN_STAMPS
-    unsigned long long acc_item = 0, acc_arcs = 0, acc_gather = 0, acc_commit = 0, n_steps = 0, n_items = 0;
-#endif
-    STAMP(ts_begin);
-#ifdef PSN_STAMPS
-    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
-#endif
     for (unsigned i = wave; i < nseg; i += nwaves) {
-        STAMP(ts_i0);
         const int4 it = segl[i];
         const int v = it.x;
         const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
         const bool solo = it.w & 1;
         const i64 dv = dist_of(g.dist[v]), pv = g.price[v];
-#ifdef PSN_STAMPS
-        asm volatile("" ::"v"(dv), "v"(pv), "v"(r0));  // the item, its distance and price are here
-        ++n_items;
-#endif
-        STAMP(ts_i1);
-        STAMP_ADD(acc_item, ts_i0, ts_i1);
         if (r1 - r0 <= 64u) {
             // Short rows (a job's aggregator: some fifty tasks) go one arc per lane: eight arcs per
             // lane would leave seven lanes doing all the atomics and lookups of the row one after
@@ -1029,14 +859,10 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
             if (on) hub1[0] = g.hub_of[hd1[0]];
             i64 nd1[1] = {kDistInf};
             if (on) { const i64 l = arc_len(-(i64)cs1 * S + p1 - pv, sh); if (dv + l < d1) nd1[0] = dv + l; }
-#ifdef PSN_STAMPS
-            ++n_steps;
-#endif
             gu_commit_batch<1>(g, q, dcnt, dlow, dseg, s_hmin, hd1, hub1, nd1, stamp, rot, wmax, t);
             continue;
         }
         for (unsigned h = r0; h < r1; h += kStep) {
-            STAMP(ts_s0);
             const unsigned a0 = h + lane * 8, lim8 = min(r1, h + 512), at = h + 512 + lane, limt = min(r1, h + kStep);
             int rc9[9], hd[9], cs[9];
             load9(g.rcap, a0, lim8, at, limt, rc9);
@@ -1055,13 +881,6 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                     for (int j = 0; j < 9; ++j) { hd[j] = 0; cs[j] = 0; }
                 }
             }
-#ifdef PSN_STAMPS
-#pragma unroll
-            for (int j = 0; j < 9; ++j) asm volatile("" ::"v"(rc9[j]), "v"(hd[j]), "v"(cs[j]));
-            ++n_steps;
-#endif
-            STAMP(ts_s1);
-            STAMP_ADD(acc_arcs, ts_s0, ts_s1);
             // Rows made of aligned groups of parallel arcs (a machine row: eight slot arcs per class)
             // give every lane one run plus its tail arc.  When the whole wave sees that shape, two
             // candidates per lane are worked out and committed instead of going nine wide.
@@ -1081,11 +900,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                 hub2[1] = on1 ? g.hub_of[hd2[1]] : -1;
                 if (on0) { const i64 l = arc_len(-(i64)c0 * S + p0 - pv, sh); if (dv + l < d0) nd2[0] = dv + l; }
                 if (on1) { const i64 l = arc_len(-(i64)cs[8] * S + p1 - pv, sh); if (dv + l < d1) nd2[1] = dv + l; }
-                STAMP(ts_f2);
-                STAMP_ADD(acc_gather, ts_s1, ts_f2);
                 gu_commit_batch<2>(g, q, dcnt, dlow, dseg, s_hmin, hd2, hub2, nd2, stamp, rot, wmax, t);
-                STAMP(ts_f3);
-                STAMP_ADD(acc_commit, ts_f2, ts_f3);
                 continue;
             }
             i64 pu[9], du[9], nd[9];
@@ -1116,18 +931,9 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                 }
                 if (!(last && run_cost != INT32_MIN)) hub[j] = -1;
             }
-#ifdef PSN_STAMPS
-#pragma unroll
-            for (int j = 0; j < 9; ++j) asm volatile("" ::"v"(nd[j]), "v"(hub[j]));
-#endif
-            STAMP(ts_s2);
-            STAMP_ADD(acc_gather, ts_s1, ts_s2);
             gu_commit_batch<9>(g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
-            STAMP(ts_s3);
-            STAMP_ADD(acc_commit, ts_s2, ts_s3);
         }
     }
-    STAMP(ts_wave_items);
     const int2 *lowl = g.fr_low[src];
     const unsigned nlow_round = (nlow + 63) & ~63u;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow_round; i += gridDim.x * kBlock) {
@@ -1159,9 +965,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
         }
         gu_commit_batch<(int)kLowMax>(g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
     }
-    STAMP(ts_lane_items);
     __syncthreads();  // hub minima of the whole workgroup are in LDS
-    STAMP(ts_barrier);
     // The end of the sweep is a handful of independent read-modify-writes (hub distance, the two
     // queue counters, the largest-distance slot, the work counters).  Their first halves are all
     // issued before any result is used, so the wave waits one round trip for them, not five.
@@ -1191,7 +995,6 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                 append_split(dcnt, dseg, u, g.row[u], g.row[u + 1], rot ^ (unsigned)u);  // once per hub and sweep: not worth two registers held through the sweep
         }
     }
-    STAMP(ts_hubs);
     base_low = __shfl(base_low, 0);
     base_seg = __shfl(base_seg, 0);
     for (unsigned i = lane; i < q.nlow; i += 64) dlow[base_low + i] = q.low[i];
@@ -1208,16 +1011,6 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
         if (n_relax) tslot[kTallyGuRelax] = t_relax + n_relax;
         if (n_iters) tslot[kTallyGuIters] = t_iters + n_iters;
     }
-#ifdef PSN_STAMPS
-    if (g.stamps && nseg >= kStampExpandMin && nseg < kStampExpandMax && lane == 0) {
-        __builtin_amdgcn_s_waitcnt(0);
-        const unsigned long long ts_end = stamp_now();
-        unsigned long long *o = g.stamps + (size_t)wave * 16;
-        o[0] = ts_begin; o[1] = ts_wave_items; o[2] = ts_lane_items; o[3] = ts_barrier; o[4] = ts_hubs; o[5] = ts_end;
-        o[6] = n_items; o[7] = n_steps; o[8] = acc_item; o[9] = acc_arcs; o[10] = acc_gather; o[11] = acc_commit;
-        o[12] = rt_begin; o[13] = nseg; o[14] = (unsigned long long)k; o[15] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
 }
 
 // dist = 0 at deficits (they seed frontier 0), "infinite" elsewhere.
@@ -1225,9 +1018,6 @@ __device__ __forceinline__ void gu_init_body(const DevGraph &g) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_init_on) return;
     __shared__ AppendLds s_app;
-#ifdef PSN_PROBE_APPEND
-    if (threadIdx.x == 0) s_app.probe = nullptr;
-#endif
     const unsigned rot = mix32(ct->epoch, 0x5EEDu);
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < kGrid * (kBlock / 64); i += gridDim.x * kBlock) g.dmax_part[i] = 0;
     const int span = kBlock * kVpt;
