@@ -74,6 +74,11 @@ struct psn_ctx {
     unsigned long long serial = 0, upload_gen = 0;
     // vertex cover behind the cost scale: flags per vertex, size found, size the current scale allows for
     unsigned char *d_in_cover = nullptr;
+    unsigned char *d_cls = nullptr;    // vertex class bytes (the device copy the kernels read; k_lean_flag sets a bit in them)
+    unsigned *d_lean_stop = nullptr;
+    int *d_hub_of = nullptr;           // hub slots from the host, pull marks from k_pull_mark
+    int2 *d_pull_list = nullptr;
+    unsigned *d_pull_cnt = nullptr;
     long long cover_size = 0, cover_cap = 0;
     struct GroupCache *gcache = nullptr;  // lockstep group led by this context, kept between batch calls
 };
@@ -168,7 +173,7 @@ void free_graph_buffers(psn_ctx *c) {
     ++c->upload_gen;
     c->uploaded = c->solved = false;
     c->d_place = c->d_slot_machine = nullptr;
-    c->d_in_cover = nullptr; c->cover_size = c->cover_cap = 0;
+    c->d_in_cover = nullptr; c->d_cls = nullptr; c->d_lean_stop = nullptr; c->d_hub_of = nullptr; c->d_pull_list = nullptr; c->d_pull_cnt = nullptr; c->cover_size = c->cover_cap = 0;
     c->d_allow = nullptr; c->allow_words = c->allow_classes = 0; c->allow_on = false;
     c->place_count = c->slot_stride = c->slot_classes = 0;
 }
@@ -283,6 +288,50 @@ __global__ void k_cover_mark(const unsigned *row, int n, unsigned m2, const int 
         if (!(dh > dt || (dh == dt && h > t))) in_cover[t] = 1;  // a neighbour that is not "larger": t cannot stay out
     }
 }
+// Rows made of aligned groups of 8 parallel arcs (the 8 slot arcs between a task class and a
+// machine, seen from either end) let the expansion sweep fetch one head per lane instead of eight
+// and take a two-candidate path.  lean_stop[v] = first arc index past the leading such groups of
+// v's row; a vertex that is one wave item gets the kClsLean bit when every step of its row
+// qualifies (the 8-arc parts of its steps all lie inside that prefix).
+__global__ void k_lean_init(const unsigned *row, int n, unsigned *lean_stop) {
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) lean_stop[v] = row[v] + ((row[v + 1] - row[v]) & ~7u);
+}
+__global__ void k_lean_scan(const unsigned *row, unsigned m2, const int *head, const int *tail, unsigned *lean_stop) {
+    for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < m2; a += gridDim.x * kBlock) {
+        const int v = tail[a];
+        if (((a - row[v]) & 7u) || a + 8 > row[v + 1]) continue;  // not the first arc of a complete group
+        bool same = true;
+        for (int j = 1; j < 8; ++j) same &= head[a + j] == head[a];
+        if (!same) atomicMin(&lean_stop[v], a);
+    }
+}
+__global__ void k_lean_flag(const unsigned *row, int n, const unsigned *lean_stop, unsigned char *cls) {
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
+        const unsigned char c = cls[v] & kClsMask;
+        const unsigned deg = row[v + 1] - row[v];
+        bool lean = false;
+        if (c == kClsMed && deg > 0) {
+            const unsigned last_step = (deg - 1) / kStep * kStep;  // offset of the row's last step
+            lean = lean_stop[v] - row[v] >= min(deg, last_step + 512u);
+        }
+        cls[v] = c | (lean ? kClsLean : 0);
+    }
+}
+// Pull vertices (DevGraph::pull_list): degree <= kLowMax and every neighbour of a larger degree.
+__global__ void k_pull_mark(const unsigned *row, int n, const int *head, const unsigned char *cls, int *hub_of, int2 *pull_list,
+                            unsigned *pull_cnt) {
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
+        if ((cls[v] & kClsMask) != kClsLow) continue;
+        const unsigned r0 = row[v], r1 = row[v + 1];
+        bool ok = r1 > r0;
+        for (unsigned a = r0; a < r1; ++a) {
+            const int h = head[a];
+            if ((unsigned)h >= (unsigned)n || (cls[h] & kClsMask) == kClsLow) ok = false;
+        }
+        hub_of[v] = ok ? kHubPull : -1;
+        if (ok) pull_list[atomicAdd(pull_cnt, 1u)] = make_int2(v | (int)((r1 - r0) << 28), (int)r0);
+    }
+}
 __global__ void k_cover_count(const unsigned char *in_cover, int n, unsigned *out) {
     unsigned c = 0;
     for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) c += in_cover[v];
@@ -327,16 +376,21 @@ __global__ void k_max_violation(DevGraph g, i64 *out) {
     if ((threadIdx.x & 63) == 0 && mx > 0) __hip_atomic_fetch_max(out, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Sum of the supplies of the resident network (psn_update_supplies may have unbalanced them).
-__global__ void k_sum_supply(const i64 *supply, int n, i64 *out) {
+// Sum of the supplies of the resident network (psn_update_supplies may have unbalanced them) and
+// the number of vertices that hold supply.
+__global__ void k_sum_supply(const i64 *supply, int n, i64 *out, i64 *n_sources) {
     i64 sm = 0;
-    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) sm += supply[v];
+    unsigned src = 0;
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) { sm += supply[v]; src += supply[v] > 0; }
     sm = (i64)wave_sum_u64((unsigned long long)sm);
+    src = wave_sum_u32(src);
     if ((threadIdx.x & 63) == 0 && sm) __hip_atomic_fetch_add(out, sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0 && src) __hip_atomic_fetch_add(n_sources, (i64)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 constexpr int kScalarSlots = 40;
-constexpr int kSupplySumSlot = 38;  // d_scalar: [0] total cost, [1] max violation, [2..35] cost statistics, [38] supply sum
+constexpr int kSupplySumSlot = 38;  // d_scalar: [0] total cost, [1] max violation, [2..35] cost statistics, [36] vertices with supply, [38] supply sum
+constexpr int kSourcesSlot = 36;
 
 // Marks and counts the vertex cover of the resident network on the context's stream; the count is
 // on its way to h_flag[2] when this returns (d_scalar slot kCoverSlot is the device counter).
@@ -349,6 +403,13 @@ int launch_cover(psn_ctx *c) {
     if (g.m2) hipLaunchKernelGGL(k_cover_mark, dim3(kGrid), dim3(kBlock), 0, c->stream, g.row, g.n, g.m2, g.head, g.tail, c->d_in_cover);
     hipLaunchKernelGGL(k_cover_count, dim3(std::max(1, std::min(256, (g.n + kBlock - 1) / kBlock))), dim3(kBlock), 0, c->stream, c->d_in_cover, g.n, d_cnt);
     HIPCHK(c, hipMemcpyAsync(c->h_flag + 2, d_cnt, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    // the other table that follows from the heads alone: where rows stop being groups of parallel arcs
+    const int gvn = std::max(1, std::min(kGrid, (g.n + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(k_lean_init, dim3(gvn), dim3(kBlock), 0, c->stream, g.row, g.n, c->d_lean_stop);
+    if (g.m2) hipLaunchKernelGGL(k_lean_scan, dim3(kGrid), dim3(kBlock), 0, c->stream, g.row, g.m2, g.head, g.tail, c->d_lean_stop);
+    hipLaunchKernelGGL(k_lean_flag, dim3(gvn), dim3(kBlock), 0, c->stream, g.row, g.n, c->d_lean_stop, c->d_cls);
+    HIPCHK(c, hipMemsetAsync(c->d_pull_cnt, 0, sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(k_pull_mark, dim3(gvn), dim3(kBlock), 0, c->stream, g.row, g.n, g.head, c->d_cls, c->d_hub_of, c->d_pull_list, c->d_pull_cnt);
     return PSN_OK;
 }
 // The cost scale that goes with a cover of `cover` vertices, with room for the cover to grow a
@@ -494,20 +555,22 @@ static int setup_rows(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off)
     unsigned *d_row, *d_hub_row0; int *d_head, *d_rev, *d_tail, *d_hub_of, *d_hub_vertex, *d_hub_seg0, *d_seg1_of; unsigned char *d_cls;
     int rc;
 #define A(p, cnt) if ((rc = dalloc(c, &(p), (size_t)(cnt))) != PSN_OK) { free_graph_buffers(c); return rc; }
-    A(d_row, n + 1) A(d_head, m2) A(c->d_cost, m2) A(d_rev, m2) A(d_tail, m2) A(c->d_ocap, m2) A(d_cls, n) A(d_hub_of, n) A(d_hub_vertex, kMaxHubs)
+    A(d_row, n + 1) A(d_head, m2 + kArcPad) A(c->d_cost, m2 + kArcPad) A(d_rev, m2 + kArcPad) A(d_tail, m2) A(c->d_ocap, m2 + kArcPad) A(d_cls, n) A(d_hub_of, n) A(d_hub_vertex, kMaxHubs)
     A(d_hub_row0, kMaxHubs) A(d_hub_seg0, kMaxHubs) A(d_seg1_of, n) A(g.seg_scan, n_hub_segs) A(g.seg_add[0], n_hub_segs) A(g.seg_add[1], n_hub_segs)
-    A(g.cap, m2) A(g.rcap, m2) A(g.price, n) A(g.excess, n) A(g.cand, n) A(g.dist, n)
-    A(c->d_supply, n) A(c->d_scalar, kScalarSlots) A(c->d_in_cover, n)
+    A(g.cap, m2 + kArcPad) A(g.rcap, m2 + kArcPad) A(g.price, n) A(g.excess, n) A(g.cand, n) A(g.dist, n)
+    A(c->d_supply, n) A(c->d_scalar, kScalarSlots) A(c->d_in_cover, n) A(c->d_lean_stop, n) A(c->d_pull_list, n) A(c->d_pull_cnt, 1)
     for (int i = 0; i < 2; ++i) { A(g.list_low[i], n) A(g.list_seg[i], (size_t)n + high_items) }
     for (int i = 0; i < 3; ++i) { A(g.fr_low[i], n) A(g.fr_seg[i], (size_t)n + high_items) }
-    c->tally_slots = kGrid * (kBlock / 64);
-    A(g.dmax_part, (size_t)kGrid * (kBlock / 64))
+    c->tally_slots = kSweepWaves;
+    A(g.dmax_part, (size_t)kSweepWaves)
     A(g.tally, (size_t)c->tally_slots * kTallyN) A(c->d_tally_out, kTallyN) A(g.ctrl, 1)
+    i64 *d_spare;
+    A(d_spare, 8)
     if (std::getenv("PSN_TRACE")) { A(g.dbg, kDbgCap) A(g.dbg_cnt, 1) }
 #undef A
     c->d_head = d_head; c->d_rev = d_rev;
-    g.row = d_row; g.head = d_head; g.cost = c->d_cost; g.rev = d_rev; g.tail = d_tail; g.ocap = c->d_ocap; g.cls = d_cls;
-    g.hub_of = d_hub_of; g.hub_vertex = d_hub_vertex; g.nhubs = nhubs;
+    g.row = d_row; g.head = d_head; g.cost = c->d_cost; g.rev = d_rev; g.tail = d_tail; g.ocap = c->d_ocap; g.cls = d_cls; c->d_cls = d_cls; g.lean_stop = c->d_lean_stop;
+    g.hub_of = d_hub_of; c->d_hub_of = d_hub_of; g.pull_list = c->d_pull_list; g.pull_cnt = c->d_pull_cnt; g.hub_vertex = d_hub_vertex; g.nhubs = nhubs;
     g.hub_row0 = d_hub_row0; g.hub_seg0 = d_hub_seg0; g.seg1_of = d_seg1_of; g.n_hub_segs = n_hub_segs;
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(d_row, row.data(), sizeof(unsigned) * ((size_t)n + 1), hipMemcpyHostToDevice, s));
@@ -518,6 +581,8 @@ static int setup_rows(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off)
     HIPCHK(c, hipMemcpyAsync(d_hub_seg0, hub_seg0.data(), sizeof(int) * (size_t)kMaxHubs, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_seg1_of, seg1_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemsetAsync(g.price, 0, sizeof(i64) * (size_t)n, s));
+    HIPCHK(c, hipMemsetAsync(d_spare, 0, sizeof(i64) * 8, s));
+    g.spare = d_spare;
     if (m2 > 0) hipLaunchKernelGGL(k_fill_tail, dim3(kGrid), dim3(kBlock), 0, s, d_row, (int)n, (unsigned)m2, d_tail);
     HIPCHK(c, hipStreamSynchronize(s));  // the staging vectors above die at return
     return PSN_OK;
@@ -1020,7 +1085,7 @@ static int solve_prepare(psn_ctx *c, hipStream_t s, bool warm, i64 *h_scalar) {
     if (g.dbg_cnt) HIPCHK(c, hipMemsetAsync(g.dbg_cnt, 0, sizeof(unsigned), s));
     if (!warm) hipLaunchKernelGGL(k_cost_stats, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 2);
     if (warm) hipLaunchKernelGGL(k_max_violation, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 1);
-    hipLaunchKernelGGL(k_sum_supply, dim3(std::max(1, std::min(64, (g.n + kBlock - 1) / kBlock))), dim3(kBlock), 0, s, c->d_supply, g.n, c->d_scalar + kSupplySumSlot);
+    hipLaunchKernelGGL(k_sum_supply, dim3(std::max(1, std::min(64, (g.n + kBlock - 1) / kBlock))), dim3(kBlock), 0, s, c->d_supply, g.n, c->d_scalar + kSupplySumSlot, c->d_scalar + kSourcesSlot);
     HIPCHK(c, hipMemcpyAsync(h_scalar, c->d_scalar, kScalarSlots * sizeof(i64), hipMemcpyDeviceToHost, s));
     return PSN_OK;
 }
@@ -1029,6 +1094,11 @@ static int solve_start(psn_ctx *c, hipStream_t s, bool warm, const i64 *h_scalar
     const DevGraph &g = c->g;
     Ctrl init{};
     init.alpha_log2 = c->cfg.alpha_log2;
+    // phases other than the last stop at about 1 % of the sources still active (see k_begin)
+    int tail_div = kTailDiv;
+    if (const char *ev = std::getenv("PSN_TAIL_DIV")) tail_div = std::max(1, atoi(ev));
+    init.tail_items = (int)std::min<i64>(1 << 20, h_scalar[kSourcesSlot] / tail_div);
+    if (const char *ev = std::getenv("PSN_TAIL_ITEMS")) init.tail_items = std::max(0, atoi(ev));
     int shift0;
     if (!warm) {
         // Zero flow with zero prices is 0-optimal when no usable arc has a negative cost, so the
@@ -1662,5 +1732,41 @@ int psn_placements_device_ptr(psn_ctx *c, void **dptr, int64_t *count) {
     *count = c->place_count;
     return PSN_OK;
 }
+
+#ifdef PSN_UBENCH
+// Development builds only: time expansion-sweep variants on the state a finished solve left.
+// For every target iteration kt in [1, max_kt]: seed the sink as the only deficit, run the
+// shipping sweep for iterations 0..kt-1 and the variant at kt.  Read the durations from a
+// kernel trace.  The context's solution is destroyed.
+int psn_debug_gu_bench(psn_ctx *c, int variant, int reps, int eps_shift, int sink, int max_kt) {
+    if (!c || !c->uploaded) return PSN_ESTATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const DevGraph &g = c->g;
+    const int gv = std::max(1, std::min(kGrid, (g.n + kBlock * kVpt - 1) / (kBlock * kVpt)));
+    const int gs = (int)std::max<long long>(32, std::min<long long>(kGrid, (c->m2 + kBlock * 16 - 1) / (kBlock * 16)));
+    hipStream_t s = c->stream;
+    for (int r = 0; r < reps; ++r)
+        for (int kt = 1; kt <= max_kt; ++kt) {
+            hipLaunchKernelGGL(k_ub_seed, dim3(1), dim3(1), 0, s, g, sink, eps_shift);
+            hipLaunchKernelGGL(k_gu_init, dim3(gv), dim3(kBlock), 0, s, g);
+            for (int k = 0; k < kt; ++k) hipLaunchKernelGGL(k_gu_expand, dim3(gs), dim3(kBlock), 0, s, g, k);
+            switch (variant) {
+            case 0: hipLaunchKernelGGL(k_ub_expand<0>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
+            case 1: hipLaunchKernelGGL(k_ub_expand<1>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
+            case 2: hipLaunchKernelGGL(k_ub_expand<2>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
+            case 4: hipLaunchKernelGGL(k_ub_expand<4>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
+            case 5: hipLaunchKernelGGL(k_ub_expand<5>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
+            case 7: hipLaunchKernelGGL(k_ub_expand3<7>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
+            case 8: hipLaunchKernelGGL(k_ub_expand3<8>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
+            case 9: hipLaunchKernelGGL(k_ub_expand3<1>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
+            case 6: hipLaunchKernelGGL(k_ub_expand<6>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
+            case 3: hipLaunchKernelGGL(k_ub_expand_wide<3>, dim3(gs / 4), dim3(1024), 0, s, g, kt); break;
+            default: return PSN_EINVAL;
+            }
+        }
+    HIPCHK(c, hipStreamSynchronize(s));
+    return PSN_OK;
+}
+#endif
 
 }  // extern "C"

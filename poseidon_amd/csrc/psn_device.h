@@ -12,16 +12,22 @@ typedef long long i64;
 
 constexpr int kBlock = 256;      // threads per workgroup (4 waves)
 constexpr int kGrid = 1024;      // workgroups per sweep launch: 16 waves per CU on 256 CUs
+constexpr int kSweepWaves = kGrid * 4;  // per-wave slots (work counters, largest distance): waves of the largest sweep grid
 constexpr unsigned kLowMax = 4;  // degree <= kLowMax: one lane per vertex
 constexpr unsigned kStep = 576;  // arcs per wave step: 8 consecutive per lane + one strided
+constexpr unsigned kArcPad = 8;   // spare entries after the arc arrays: a lane may load its 8 arcs past the end of a range
 constexpr unsigned kWSeg = 2 * kStep;  // arcs per wave work item; larger vertices are split into several items
 constexpr unsigned kMedMax = kWSeg;  // degree <= kMedMax: the whole vertex is one wave item
 constexpr unsigned kQCap = 256;  // entries per per-wave LDS frontier staging queue
 constexpr int kVpt = 2;          // vertices per thread in the vertex sweeps
 constexpr int kMaxVertices = 1 << 28;  // lane items pack the degree above bit 28
 constexpr int kClsLow = 0, kClsMed = 1, kClsHigh = 2;  // vertex classes by degree
+constexpr int kClsMask = 3;      // the class in a cls[] byte
+constexpr int kClsLean = 4;      // cls[] bit: every step of the row is made of aligned groups of 8 parallel arcs
 constexpr int kClsSeg = 1;       // counter slot of the (vertex, segment) item lists (slot 0: lane list)
+constexpr int kHubPull = -2;     // hub_of[] value of a pull vertex (see DevGraph::pull_list); -1: an ordinary vertex
 constexpr int kMaxHubs = 128;    // highest-degree vertices whose atomics are pre-combined in LDS per workgroup
+constexpr int kTailDiv = 128;     // Ctrl::tail_items = vertices with supply / kTailDiv
 constexpr int kGuIters = 12;     // frontier expansions per replay (multiple of 3)
 constexpr int PSN_EINFEASIBLE_DEV = -4;
 
@@ -35,12 +41,14 @@ enum { kTallyScans = 0, kTallyPushes, kTallyRelabels, kTallyVisits, kTallyGuScan
 struct Ctrl {
     i64 eps;
     int eps_shift, alpha_log2;
+    int tail_items;  // a phase that is not the last one ends when its work list has shrunk to this many items
     int need_sat, need_gu, gu_active;
     int sat_on, gu_on, gu_init_on, rounds_on;
     int done, error;
     unsigned epoch, gu_stamp_base;
     unsigned list_cnt[2][4];
     unsigned fr_cnt[3][4];
+    int gu_phase[2];  // global update, read by expansion k at [k & 1], written at [(k + 1) & 1]: 0 expanding, 1 the pull sweep just ran, 2 converged
     unsigned long long tally_refines, tally_gus;
 };
 
@@ -55,8 +63,15 @@ struct DevGraph {
     i64 scale;  // S = n + 1
     const unsigned *row;
     const int *head, *cost, *rev, *tail, *ocap;
-    const unsigned char *cls;
-    const int *hub_of;      // hub slot of a vertex, -1 for the rest
+    const unsigned char *cls;  // class | kClsLean
+    const unsigned *lean_stop;  // per vertex: first arc index past the leading aligned groups of 8 parallel arcs of its row
+    const int *hub_of;      // hub slot of a vertex; kHubPull for a pull vertex; -1 for the rest
+    // Pull vertices: degree <= kLowMax and no neighbour of degree <= kLowMax (the tasks of a scheduling
+    // network).  The frontier expansions of a global update do not relax them; when the frontier
+    // runs dry one sweep over this static list works their distances out from their neighbours'
+    // (no atomics: each is written by its own lane) and relaxes their neighbours in turn.
+    const int2 *pull_list;  // lane items
+    const unsigned *pull_cnt;
     const int *hub_vertex;  // vertex of each hub slot
     const int *seg1_of;     // per vertex: 1 + index of its first segment's bound slots when it is a hub, else 0
     int nhubs;
@@ -77,6 +92,7 @@ struct DevGraph {
     int4 *fr_seg[3];
     unsigned long long *tally;
     Ctrl *ctrl;
+    const void *spare;  // 64 bytes of zeros: where a lane that needs no value points its load
     int4 *dbg;          // optional launch trace (kind, k, lane-list size, item-list size); null when off
     unsigned *dbg_cnt;
 };

@@ -35,6 +35,17 @@ __device__ __forceinline__ i64 dist_of(i64 packed) { return packed >> 16; }
 
 typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));
 
+// Predicated loads without control flow.  `need ? *p : dflt` written as a branch around the load
+// lets the compiler sink whatever consumes the value into the branch, and the wait for the load
+// with it: every such load then becomes a memory round trip of its own (nine in a row for the
+// per-arc lookups of a lane).  Selecting the address instead keeps the loads unconditional: a
+// lane that does not need the value reads a spare word (one shared cache line per wave) and the
+// result is selected after all loads of the step have been issued.
+template <typename T>
+__device__ __forceinline__ T ld_sel(bool need, const T *p, const void *spare) {
+    return *(need ? p : static_cast<const T *>(spare));
+}
+
 // ------------------------------------------------------------------ wave primitives
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
@@ -95,10 +106,11 @@ __device__ __forceinline__ void tally_flush(const DevGraph &g, Tally &t) {
 // ------------------------------------------------------------------------ work items
 // Lane item  (degree <= kLowMax): int2 { v | degree << 28, first arc }.
 // Wave item  (everything else):   int4 { v, first arc, end arc, flags } covering at most
-// kWSeg arcs; flags bit 0 = the item is the whole vertex ("solo").  Items carry their arc
+// kWSeg arcs; flags bit 0 = the item is the whole vertex ("solo"), bit 1 (solo items of the
+// global-update frontier) = the row is made of aligned groups of 8 parallel arcs.  Items carry their arc
 // range so that a sweep does not pay a dependent row-offset load before it can stream.
 __device__ __forceinline__ int2 low_item(int v, unsigned r0, unsigned r1) { return make_int2(v | (int)((r1 - r0) << 28), (int)r0); }
-__device__ __forceinline__ int4 solo_item(int v, unsigned r0, unsigned r1) { return make_int4(v, (int)r0, (int)r1, 1); }
+__device__ __forceinline__ int4 solo_item(int v, unsigned r0, unsigned r1, bool lean = false) { return make_int4(v, (int)r0, (int)r1, lean ? 3 : 1); }
 // A vertex larger than one item: its segments, starting at a per-round rotated one so that
 // vertices with common neighbours do not all begin at the same arcs.
 // flags >> 1 = 1 + index of the segment's bound slots when the vertex is a hub (seg1 = 1 + index
@@ -146,7 +158,7 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
     // the same atomic; *extra_base receives the first of them.
     unsigned nl = 0, ns = 0;
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) { nl += take[i] && cls[i] == kClsLow; ns += take[i] && cls[i] == kClsMed; }
+    for (int i = 0; i < VPT; ++i) { nl += take[i] && (cls[i] & kClsMask) == kClsLow; ns += take[i] && (cls[i] & kClsMask) == kClsMed; }
     const unsigned il = wave_incl_scan_u32(nl), is = wave_incl_scan_u32(ns);
     const int w = threadIdx.x >> 6;
     if (lane_id() == 63) { lds.sums[0][w] = il; lds.sums[1][w] = is; }
@@ -154,7 +166,7 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {  // stage the split vertices
-        if (take[i] && cls[i] == kClsHigh) {
+        if (take[i] && (cls[i] & kClsMask) == kClsHigh) {
             const unsigned at = __hip_atomic_fetch_add(&lds.n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const unsigned vrot = rot ^ (unsigned)v[i] * 0x9E3779B9u;
             if (at < (unsigned)kSplitCap) {
@@ -195,8 +207,8 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         if (!take[i]) continue;
-        if (cls[i] == kClsLow) lowl[pl++] = low_item(v[i], r0[i], r1[i]);
-        else if (cls[i] == kClsMed) segl[ps++] = solo_item(v[i], r0[i], r1[i]);
+        if ((cls[i] & kClsMask) == kClsLow) lowl[pl++] = low_item(v[i], r0[i], r1[i]);
+        else if ((cls[i] & kClsMask) == kClsMed) segl[ps++] = solo_item(v[i], r0[i], r1[i], (cls[i] & kClsLean) != 0);
     }
     if (extra_base) *extra_base = lds.sums[1][kBlock / 64] + med_total + nsplit_segs;
     if (nsplit) {
@@ -264,16 +276,21 @@ __device__ __forceinline__ void hub_flush_push(const DevGraph &g, const HubAcc &
 // The ninth arc lets a 513-arc row (64 classes x 8 slots + the sink arc of a machine) go
 // through in one step.  Slot j of a lane: arc index arc9(a0, at, j).
 __device__ __forceinline__ unsigned arc9(unsigned a0, unsigned at, int j) { return j < 8 ? a0 + (unsigned)j : at; }
-__device__ __forceinline__ void load9(const int *p, unsigned a0, unsigned lim8, unsigned at, unsigned limt, int (&x)[9]) {
-    if (a0 + 7 < lim8) {
-        const int4u lo = *reinterpret_cast<const int4u *>(p + a0);
-        const int4u hi = *reinterpret_cast<const int4u *>(p + a0 + 4);
-        x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = a0 + j < lim8 ? p[a0 + j] : 0;
-    }
-    x[8] = at < limt ? p[at] : 0;
+__device__ __forceinline__ void load9(const int *p, unsigned a0, unsigned lim8, unsigned at, unsigned limt, int (&x)[9],
+                                      bool need = true, unsigned safe = 0) {
+    // No control flow around the loads (see ld_sel): a lane outside the range, or one that does not
+    // need the array, reads at `safe` (an index inside the arrays, the same for the whole wave).
+    // A lane whose 8 arcs straddle the end of the range reads up to 7 entries past it: the arc
+    // arrays are allocated with kArcPad spare entries.
+    const bool in8 = need && a0 < lim8, intl = need && at < limt;
+    const int *q = p + (in8 ? a0 : safe);
+    const int4u lo = *reinterpret_cast<const int4u *>(q);
+    const int4u hi = *reinterpret_cast<const int4u *>(q + 4);
+    const int tl = p[intl ? at : safe];
+    const unsigned left = in8 ? lim8 - a0 : 0u;
+    x[0] = left > 0 ? lo.x : 0; x[1] = left > 1 ? lo.y : 0; x[2] = left > 2 ? lo.z : 0; x[3] = left > 3 ? lo.w : 0;
+    x[4] = left > 4 ? hi.x : 0; x[5] = left > 5 ? hi.y : 0; x[6] = left > 6 ? hi.z : 0; x[7] = left > 7 ? hi.w : 0;
+    x[8] = intl ? tl : 0;
 }
 __device__ __forceinline__ unsigned count9(unsigned a0, unsigned lim8, unsigned at, unsigned limt) {
     return (a0 < lim8 ? min(8u, lim8 - a0) : 0u) + (at < limt ? 1u : 0u);
@@ -290,8 +307,11 @@ __device__ __forceinline__ void gather9(const int (&hd)[9], const bool (&need)[9
         reuse[j] = j > 0 && j < 8 && have[j > 0 ? j - 1 : 0] && hd[j] == hd[j > 0 ? j - 1 : 0];
         have[j] = reuse[j] || need[j];
     }
+    T raw[9];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) out[j] = (need[j] && !reuse[j]) ? load(hd[j]) : dflt;  // all loads in flight together
+    for (int j = 0; j < 9; ++j) raw[j] = load(need[j] && !reuse[j], hd[j]);  // all loads in flight together, none behind a branch
+#pragma unroll
+    for (int j = 0; j < 9; ++j) out[j] = (need[j] && !reuse[j]) ? raw[j] : dflt;
 #pragma unroll
     for (int j = 1; j < 8; ++j) if (reuse[j]) out[j] = out[j - 1];
 }
@@ -394,7 +414,7 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
         bool live[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) live[j] = cp[j] > 0;
-        gather9(hd, live, ph, (i64)0, [&](int v) { return g.price[v]; });
+        gather9(hd, live, ph, (i64)0, [&](bool c, int v) { return ld_sel(c, &g.price[v], g.spare); });
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             if (live[j]) {
@@ -565,7 +585,7 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
             const bool in = v[i] < g.n;
             e[i] = in ? g.excess[v[i]] : 0;
             c[i] = in ? g.cand[v[i]] : kInf;
-            cls[i] = in ? (int)g.cls[v[i]] : 0;
+            cls[i] = in ? (int)(g.cls[v[i]] & kClsMask) : 0;  // no lean bit in the push lists: their flags hold bound slots
             p[i] = in ? g.price[v[i]] : 0;
             r0[i] = in ? g.row[v[i]] : 0;
             r1[i] = in ? g.row[v[i] + 1] : 0;
@@ -719,12 +739,18 @@ __device__ __forceinline__ i64 arc_len(i64 rc, int sh) {
     return l < 0 ? 0 : (l > kLenMax ? kLenMax : l);
 }
 
+// A value the optimiser cannot see through.  `x = dflt; if (c) x = atomic(...)` with a constant
+// default lets it fold whatever consumes x into the branch, and the wait for the atomic's result
+// with it: NJ atomics then take NJ round trips one after the other.
+__device__ __forceinline__ i64 opaque(i64 x) { asm("" : "+v"(x)); return x; }
+
 // Commit up to NJ tentative distances per lane (nd[j] == kDistInf: none) and queue the
-// vertices this wave is the first to improve in this iteration.  Every memory round trip
-// (atomic min, stamp exchange, class + row lookup) is issued for all NJ candidates before
-// any result is used, so a lane pays each latency once per step, not once per arc.
+// vertices this wave is the first to improve in this iteration.  The atomic mins of all NJ
+// candidates and the class / row lookups their vertices will need if they have to be queued are
+// issued together, before any result is used: a lane pays one round trip per step for the
+// commit, not one per arc and not a second one for the lookups.
 // Hubs (hub[j] >= 0) are only lowered in LDS here; the workgroup commits them at the end.
-template <int NJ>
+template <int NJ, unsigned QC = kQCap>
 __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, unsigned *dcnt, int2 *dlow, int4 *dseg, i64 *hub_min,
                                                 const int (&hd)[NJ], const int (&hub)[NJ], const i64 (&nd)[NJ], unsigned stamp,
                                                 unsigned rot, i64 &wmax, Tally &t) {
@@ -732,43 +758,46 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
 #pragma unroll
     for (int j = 0; j < NJ; ++j) anyc |= nd[j] < kDistInf;
     if (!__ballot(anyc)) return;
+    const i64 none = opaque(kNegInf);
     i64 old[NJ];
+    bool far[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        old[j] = kNegInf;
-        if (nd[j] < kDistInf) {
-            if (hub[j] >= 0) lds_min(&hub_min[hub[j]], nd[j]);
-            else old[j] = amin64(&g.dist[hd[j]], dist_pack(nd[j], stamp));
-        }
+        const bool c = nd[j] < kDistInf && hub[j] != kHubPull;  // pull vertices fetch their distance themselves
+        far[j] = c && hub[j] < 0;
+        old[j] = none;
+        if (c && hub[j] >= 0) lds_min(&hub_min[hub[j]], nd[j]);
+        if (far[j]) old[j] = amin64(&g.dist[hd[j]], dist_pack(nd[j], stamp));
     }
-    bool first[NJ];
+    int clsb[NJ];
+    unsigned r0[NJ], r1[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {  // in flight together with the atomics
+        clsb[j] = (int)ld_sel(far[j], &g.cls[hd[j]], g.spare);
+        r0[j] = ld_sel(far[j], &g.row[hd[j]], g.spare);
+        r1[j] = ld_sel(far[j], &g.row[hd[j] + 1], g.spare);
+    }
+    int cls[NJ];
+    unsigned nl = 0, ns = 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        // improved: the stored distance was larger (old stays -inf for "no candidate" and hubs);
-        // first: nobody lowered it during this sweep yet, so this lane queues the vertex
-        const bool improved = old[j] != kNegInf && nd[j] < dist_of(old[j]);
-        first[j] = improved && (unsigned)(old[j] & 0xFFFF) != stamp;
+        // improved: the stored distance was larger; first: nobody lowered it during this sweep
+        // yet, so this lane queues the vertex
+        const bool improved = far[j] && nd[j] < dist_of(old[j]);
+        const bool first = improved && (unsigned)(old[j] & 0xFFFF) != stamp;
         if (improved) {
             t.c[kTallyGuRelax]++;
             if (nd[j] > wmax) wmax = nd[j];
         }
+        cls[j] = first ? (clsb[j] & kClsMask) : -1;
+        nl += cls[j] == kClsLow;
+        ns += cls[j] == kClsMed;
     }
-    int cls[NJ];
-    unsigned r0[NJ], r1[NJ], nl = 0, ns = 0;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {  // first improver in this iteration queues the vertex
-        const bool enq = first[j];
-        cls[j] = enq ? (int)g.cls[hd[j]] : -1;
-        r0[j] = enq ? g.row[hd[j]] : 0;
-        r1[j] = enq ? g.row[hd[j] + 1] : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) { nl += cls[j] == kClsLow; ns += cls[j] == kClsMed; }
     if (__ballot(nl != 0)) {
         const unsigned incl = wave_incl_scan_u32(nl);
         const unsigned tot = __shfl(incl, 63);
-        if (q.nlow + tot > kQCap) waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
-        if (tot > kQCap) {  // more than the staging queue holds: straight to memory
+        if (q.nlow + tot > QC) waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
+        if (tot > QC) {  // more than the staging queue holds: straight to memory
             unsigned base = 0;
             if (lane_id() == 0) base = aadd32(&dcnt[kClsLow], tot);
             unsigned pos = __shfl(base, 0) + incl - nl;
@@ -784,17 +813,17 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
     if (__ballot(ns != 0)) {
         const unsigned incl = wave_incl_scan_u32(ns);
         const unsigned tot = __shfl(incl, 63);
-        if (q.nseg + tot > kQCap) waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);
-        if (tot > kQCap) {
+        if (q.nseg + tot > QC) waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);
+        if (tot > QC) {
             unsigned base = 0;
             if (lane_id() == 0) base = aadd32(&dcnt[kClsSeg], tot);
             unsigned pos = __shfl(base, 0) + incl - ns;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsMed) dseg[pos++] = solo_item(hd[j], r0[j], r1[j]);
+            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsMed) dseg[pos++] = solo_item(hd[j], r0[j], r1[j], (clsb[j] & kClsLean) != 0);
         } else {
             unsigned pos = q.nseg + incl - ns;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsMed) q.seg[pos++] = solo_item(hd[j], r0[j], r1[j]);
+            for (int j = 0; j < NJ; ++j) if (cls[j] == kClsMed) q.seg[pos++] = solo_item(hd[j], r0[j], r1[j], (clsb[j] & kClsLean) != 0);
             q.nseg += tot;
         }
     }
@@ -802,6 +831,41 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
     for (int j = 0; j < NJ; ++j) if (cls[j] == kClsHigh) append_split(dcnt, dseg, hd[j], r0[j], r1[j], rot ^ (unsigned)hd[j]);
 }
 
+#ifdef PSN_UBENCH
+// Timing probes of the expansion sweep (development builds only): V = 1 drops the commit of the
+// candidates, V = 2 treats every arc as having no residual capacity after loading it.
+template <int V, int NJ, unsigned QC>
+__device__ __forceinline__ void gu_commit_probe(const DevGraph &g, WaveQ &q, unsigned *dcnt, int2 *dlow, int4 *dseg, i64 *hub_min,
+                                                const int (&hd)[NJ], const int (&hub)[NJ], const i64 (&nd)[NJ], unsigned stamp,
+                                                unsigned rot, i64 &wmax, Tally &t) {
+    if constexpr (V == 1) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (nd[j] < kDistInf && nd[j] + hd[j] + hub[j] > wmax) wmax = nd[j];
+    } else if constexpr (V == 8) {
+        if (g.n < 0) gu_commit_batch<NJ, QC>(g, q, dcnt, dlow, dseg, hub_min, hd, hub, nd, stamp, rot, wmax, t);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (nd[j] < kDistInf && nd[j] + hd[j] + hub[j] > wmax) wmax = nd[j];
+    } else if constexpr (V == 6) {  // no relaxation of the task vertices of the 10 000-machine synthetic cluster
+        i64 nd2[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) nd2[j] = hd[j] >= 11665 ? kDistInf : nd[j];
+        gu_commit_batch<NJ, QC>(g, q, dcnt, dlow, dseg, hub_min, hd, hub, nd2, stamp, rot, wmax, t);
+    } else if constexpr (V == 5) {
+        i64 nd2[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) nd2[j] = hub[j] >= 0 ? kDistInf : nd[j];
+        gu_commit_batch<NJ, QC>(g, q, dcnt, dlow, dseg, hub_min, hd, hub, nd2, stamp, rot, wmax, t);
+    } else {
+        gu_commit_batch<NJ, QC>(g, q, dcnt, dlow, dseg, hub_min, hd, hub, nd, stamp, rot, wmax, t);
+    }
+}
+#define GU_COMMIT(NJ, ...) gu_commit_probe<V, NJ, QC>(__VA_ARGS__)
+#define GU_RCMASK(x) ((V == 2) ? ((x) & rc_zero) : (x))
+#else
+#define GU_COMMIT(NJ, ...) gu_commit_batch<NJ, QC>(__VA_ARGS__)
+#define GU_RCMASK(x) (x)
+#endif
+template <int V = 0, int BLOCK = kBlock, unsigned QC = kQCap>
 __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_on) return;
@@ -809,40 +873,112 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     const unsigned *cnt = ct->fr_cnt[src];
     const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg];
     if (blockIdx.x == 0 && threadIdx.x < 4) ct->fr_cnt[clr][threadIdx.x] = 0;
-    if (nlow + nseg == 0) return;
+    // What this launch does follows from words it does not write: the frontier it reads and the
+    // phase the launch before it left.  A dry frontier is followed by one sweep over the pull
+    // vertices; if that queues nothing either, the update has converged.
+    const int phase = ct->gu_phase[k & 1];
+    const unsigned npull = *g.pull_cnt;
+    const bool dry = nlow + nseg == 0;
+    const bool do_pull = phase == 0 && dry && npull != 0;
+    const int phase_out = phase == 2 ? 2 : (!dry ? 0 : (do_pull ? 1 : 2));
+    if (blockIdx.x == 0 && threadIdx.x == 0) ct->gu_phase[(k + 1) & 1] = phase_out;
+    if (phase == 2 || (dry && !do_pull)) return;
     if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
         const unsigned i = aadd32(g.dbg_cnt, 1u);
-        if (i < kDbgCap) g.dbg[i] = make_int4(2, k, (int)nlow, (int)nseg);
+        if (i < kDbgCap) g.dbg[i] = do_pull ? make_int4(3, k, (int)npull, 0) : make_int4(2, k, (int)nlow, (int)nseg);
     }
-    __shared__ int2 lds_low[(kBlock / 64) * kQCap];
-    __shared__ int4 lds_seg[(kBlock / 64) * kQCap];
+    __shared__ int2 lds_low[(BLOCK / 64) * QC];
+    __shared__ int4 lds_seg[(BLOCK / 64) * QC];
     __shared__ i64 s_hmin[kMaxHubs];
-    for (int i = threadIdx.x; i < kMaxHubs; i += kBlock) s_hmin[i] = kDistInf;
+    for (int i = threadIdx.x; i < kMaxHubs; i += BLOCK) s_hmin[i] = kDistInf;
     __syncthreads();
     WaveQ q;
-    q.low = lds_low + (threadIdx.x >> 6) * kQCap;
-    q.seg = lds_seg + (threadIdx.x >> 6) * kQCap;
+    q.low = lds_low + (threadIdx.x >> 6) * QC;
+    q.seg = lds_seg + (threadIdx.x >> 6) * QC;
     q.nlow = q.nseg = 0;
     unsigned *dcnt = ct->fr_cnt[dst];
     int2 *dlow = g.fr_low[dst];
     int4 *dseg = g.fr_seg[dst];
     const i64 S = g.scale;
     const int sh = ct->eps_shift;
+#ifdef PSN_UBENCH
+    const int rc_zero = g.n > 0 ? 0 : -1;
+#endif
     const unsigned stamp = (ct->gu_stamp_base + (unsigned)k) % 65535u + 1u;  // 16 bits, never 0
     const unsigned rot = mix32(ct->epoch, stamp);
     const int lane = lane_id();
-    const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const unsigned nwaves = (gridDim.x * kBlock) >> 6;
+    const unsigned wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const unsigned nwaves = (gridDim.x * BLOCK) >> 6;
     Tally t;
     const int my_hub_vertex = hub_vertex_of_thread(g);
     i64 wmax = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyGuIters]++;
+    if (do_pull) {
+        const int2 *pl = g.pull_list;
+        const unsigned np_round = (npull + 63) & ~63u;
+        for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < np_round; i += gridDim.x * BLOCK) {
+            const bool have = i < npull;
+            const int2 it = pl[have ? i : 0];
+            const int v = it.x & 0x0FFFFFFF;
+            const unsigned deg = have ? (unsigned)it.x >> 28 : 0u, r0 = (unsigned)it.y;
+            const i64 dcur = dist_of(g.dist[v]), pv = g.price[v];
+            int rc4[kLowMax], cp4[kLowMax], hd[kLowMax], cs[kLowMax], hub[kLowMax];
+            i64 pu[kLowMax], du[kLowMax], nd[kLowMax];
+#pragma unroll
+            for (unsigned j = 0; j < kLowMax; ++j) {  // entries past the row's end are read (the arrays have spare entries) and dropped
+                const bool ok = j < deg;
+                const int rcj = g.rcap[r0 + j], cpj = g.cap[r0 + j], hdj = g.head[r0 + j], csj = g.cost[r0 + j];
+                rc4[j] = GU_RCMASK(ok ? rcj : 0); cp4[j] = ok ? cpj : 0; hd[j] = ok ? hdj : 0; cs[j] = ok ? csj : 0;
+            }
+            t.c[kTallyGuScans] += deg;
+#pragma unroll
+            for (unsigned j = 0; j < kLowMax; ++j) {
+                const bool ok = rc4[j] > 0 || cp4[j] > 0;
+                pu[j] = ld_sel(ok, &g.price[hd[j]], g.spare); du[j] = dist_of(ld_sel(ok, &g.dist[hd[j]], g.spare));
+                const int hb = ld_sel(rc4[j] > 0, &g.hub_of[hd[j]], g.spare);
+                hub[j] = rc4[j] > 0 ? hb : -1;
+                if (!ok) du[j] = kDistInf;
+            }
+            // the vertex's own distance, over its residual arcs
+            i64 best = dcur;
+#pragma unroll
+            for (unsigned j = 0; j < kLowMax; ++j) {
+                if (cp4[j] > 0 && du[j] < kDistInf) {
+                    const i64 l = arc_len((i64)cs[j] * S + pv - pu[j], sh);
+                    if (du[j] + l < best) best = du[j] + l;
+                }
+            }
+            const bool changed = best < dcur;
+            if (changed) {
+                g.dist[v] = dist_pack(best, stamp);  // nobody else writes a pull vertex's distance
+                t.c[kTallyGuRelax]++;
+                if (best > wmax) wmax = best;
+            }
+            // and from there its neighbours', as an expansion of the vertex would
+#pragma unroll
+            for (unsigned j = 0; j < kLowMax; ++j) {
+                nd[j] = kDistInf;
+                if (changed && rc4[j] > 0) {
+                    const i64 l = arc_len(-(i64)cs[j] * S + pu[j] - pv, sh);
+                    if (best + l < du[j]) nd[j] = best + l;
+                }
+            }
+            GU_COMMIT((int)kLowMax, g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
+        }
+    }
     const int4 *segl = g.fr_seg[src];
+    int4 it_next = wave < nseg ? segl[wave] : make_int4(0, 0, 0, 0);
     for (unsigned i = wave; i < nseg; i += nwaves) {
-        const int4 it = segl[i];
-        const int v = it.x;
-        const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
-        const bool solo = it.w & 1;
+        // the item is the same for the whole wave: keep it in scalar registers, and fetch the next
+        // one now so that its round trip is over when this item is
+        const int v = __builtin_amdgcn_readfirstlane(it_next.x);
+        const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane(it_next.y), r1 = (unsigned)__builtin_amdgcn_readfirstlane(it_next.z);
+        const int flags = __builtin_amdgcn_readfirstlane(it_next.w);
+        if (i + nwaves < nseg) it_next = segl[i + nwaves];
+        const bool solo = flags & 1;
+        // first arc index past the part of v's row that is made of aligned groups of 8 parallel arcs
+        // (solo items carry the answer for their whole row in the flags)
+        const unsigned lean_stop = solo ? ((flags & 2) ? r1 : r0) : g.lean_stop[v];
         const i64 dv = dist_of(g.dist[v]), pv = g.price[v];
         if (r1 - r0 <= 64u) {
             // Short rows (a job's aggregator: some fifty tasks) go one arc per lane: eight arcs per
@@ -850,110 +986,135 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
             // the other, and such a row then costs more than a full 576-arc step.
             const unsigned a = r0 + (unsigned)lane;
             const bool in = a < r1;
-            const int rc = in ? g.rcap[a] : 0;
-            int hd1[1] = {in ? g.head[a] : 0}, hub1[1] = {-1};
-            const int cs1 = in ? g.cost[a] : 0;
+            const unsigned ac = in ? a : r0;
+            const int rc_raw = g.rcap[ac], hd_raw = g.head[ac], cs_raw = g.cost[ac];
+            const int rc = GU_RCMASK(in ? rc_raw : 0);
+            int hd1[1] = {in ? hd_raw : 0}, hub1[1] = {-1};
+            const int cs1 = in ? cs_raw : 0;
             t.c[kTallyGuScans] += in;
             const bool on = rc > 0;
-            const i64 p1 = on ? g.price[hd1[0]] : 0, d1 = on ? ld_dist(g, hd1[0]) : 0;
-            if (on) hub1[0] = g.hub_of[hd1[0]];
+            const i64 p1 = ld_sel(on, &g.price[hd1[0]], g.spare), d1 = dist_of(ld_sel(on, &g.dist[hd1[0]], g.spare));
+            const int hb1 = ld_sel(on, &g.hub_of[hd1[0]], g.spare);
+            if (on) hub1[0] = hb1;
             i64 nd1[1] = {kDistInf};
             if (on) { const i64 l = arc_len(-(i64)cs1 * S + p1 - pv, sh); if (dv + l < d1) nd1[0] = dv + l; }
-            gu_commit_batch<1>(g, q, dcnt, dlow, dseg, s_hmin, hd1, hub1, nd1, stamp, rot, wmax, t);
+            GU_COMMIT(1, g, q, dcnt, dlow, dseg, s_hmin, hd1, hub1, nd1, stamp, rot, wmax, t);
             continue;
         }
+        int rc_next[9];
+        load9(g.rcap, r0 + lane * 8, min(r1, r0 + 512), r0 + 512 + lane, min(r1, r0 + kStep), rc_next, true, r0);
         for (unsigned h = r0; h < r1; h += kStep) {
             const unsigned a0 = h + lane * 8, lim8 = min(r1, h + 512), at = h + 512 + lane, limt = min(r1, h + kStep);
-            int rc9[9], hd[9], cs[9];
-            load9(g.rcap, a0, lim8, at, limt, rc9);
-            t.c[kTallyGuScans] += count9(a0, lim8, at, limt);
-            if (solo) {  // small dense rows: fetch everything in one round trip
-                load9(g.head, a0, lim8, at, limt, hd);
-                load9(g.cost, a0, lim8, at, limt, cs);
-            } else {     // hub rows: most arcs fail the capacity test, stream 4 B per arc
-                bool anyc = false;
+            int rc9[9];
 #pragma unroll
-                for (int j = 0; j < 9; ++j) anyc |= rc9[j] > 0;
-                if (!__ballot(anyc)) { t.c[kTallyGuSkips] += count9(a0, lim8, at, limt); continue; }  // only the 4-byte capacity was read
-                if (anyc) { load9(g.head, a0, lim8, at, limt, hd); load9(g.cost, a0, lim8, at, limt, cs); }
-                else {
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) { hd[j] = 0; cs[j] = 0; }
-                }
+            for (int j = 0; j < 9; ++j) rc9[j] = GU_RCMASK(rc_next[j]);
+            if (h + kStep < r1) {  // the capacities of the item's next step travel while this one is worked on
+                const unsigned hn = h + kStep;
+                load9(g.rcap, hn + lane * 8, min(r1, hn + 512), hn + 512 + lane, min(r1, hn + kStep), rc_next, true, hn);
             }
-            // Rows made of aligned groups of parallel arcs (a machine row: eight slot arcs per class)
-            // give every lane one run plus its tail arc.  When the whole wave sees that shape, two
-            // candidates per lane are worked out and committed instead of going nine wide.
-            bool one_run = true;
+            const unsigned mine = count9(a0, lim8, at, limt);
+            t.c[kTallyGuScans] += mine;
+            if (lim8 <= lean_stop) {
+                // Aligned groups of 8 parallel arcs (the slot arcs between a task class and a machine,
+                // seen from either side): a lane's 8 consecutive arcs share their head, and since the
+                // arc length falls as the cost grows only the dearest arc with residual capacity
+                // matters.  One head and the costs are fetched, by the lanes that hold such an arc
+                // (whole-vertex items fetch them at once, without waiting for the capacities); the
+                // tail arc of the lane is a candidate of its own.
+                int cs[9];
+                int hd2[2], hub2[2];
+                const bool in8 = a0 < lim8, intl = at < limt;
+                bool need8 = in8, needt = intl;
+                if (!solo) {
+                    bool any8 = false;
 #pragma unroll
-            for (int j = 1; j < 8; ++j) one_run &= hd[j] == hd[0];
-            if (__all(one_run)) {
+                    for (int j = 0; j < 8; ++j) any8 |= rc9[j] > 0;
+                    need8 = any8;
+                    needt = rc9[8] > 0;
+                    if (!need8 && !needt) t.c[kTallyGuSkips] += mine;  // only the 4-byte capacities were read
+                    if (!__ballot(need8 || needt)) continue;
+                }
+                {
+                    const int *qc = g.cost + (need8 ? a0 : h);
+                    const int4u lo = *reinterpret_cast<const int4u *>(qc), hi = *reinterpret_cast<const int4u *>(qc + 4);
+                    cs[0] = lo.x; cs[1] = lo.y; cs[2] = lo.z; cs[3] = lo.w; cs[4] = hi.x; cs[5] = hi.y; cs[6] = hi.z; cs[7] = hi.w;
+                    cs[8] = g.cost[needt ? at : h];
+                    hd2[0] = g.head[need8 ? a0 : h];
+                    hd2[1] = g.head[needt ? at : h];
+                }
                 int c0 = INT32_MIN;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (rc9[j] > 0 && cs[j] > c0) c0 = cs[j];
-                const bool on0 = c0 != INT32_MIN, on1 = rc9[8] > 0;
-                int hd2[2] = {hd[0], hd[8]}, hub2[2];
+                for (int j = 0; j < 8; ++j) if (rc9[j] > 0 && cs[j] > c0) c0 = cs[j];  // rc9 is 0 past the end of the range
+                const bool on0 = need8 && c0 != INT32_MIN, on1 = needt && rc9[8] > 0;
                 i64 nd2[2] = {kDistInf, kDistInf};
-                const i64 p0 = on0 ? g.price[hd2[0]] : 0, p1 = on1 ? g.price[hd2[1]] : 0;
-                const i64 d0 = on0 ? ld_dist(g, hd2[0]) : 0, d1 = on1 ? ld_dist(g, hd2[1]) : 0;
-                hub2[0] = on0 ? g.hub_of[hd2[0]] : -1;
-                hub2[1] = on1 ? g.hub_of[hd2[1]] : -1;
+                const i64 p0 = ld_sel(on0, &g.price[hd2[0]], g.spare), p1 = ld_sel(on1, &g.price[hd2[1]], g.spare);
+                const i64 d0 = dist_of(ld_sel(on0, &g.dist[hd2[0]], g.spare)), d1 = dist_of(ld_sel(on1, &g.dist[hd2[1]], g.spare));
+                const int hb0 = ld_sel(on0, &g.hub_of[hd2[0]], g.spare), hb1 = ld_sel(on1, &g.hub_of[hd2[1]], g.spare);
+                hub2[0] = on0 ? hb0 : -1;
+                hub2[1] = on1 ? hb1 : -1;
                 if (on0) { const i64 l = arc_len(-(i64)c0 * S + p0 - pv, sh); if (dv + l < d0) nd2[0] = dv + l; }
                 if (on1) { const i64 l = arc_len(-(i64)cs[8] * S + p1 - pv, sh); if (dv + l < d1) nd2[1] = dv + l; }
-                gu_commit_batch<2>(g, q, dcnt, dlow, dseg, s_hmin, hd2, hub2, nd2, stamp, rot, wmax, t);
+                GU_COMMIT(2, g, q, dcnt, dlow, dseg, s_hmin, hd2, hub2, nd2, stamp, rot, wmax, t);
                 continue;
             }
-            i64 pu[9], du[9], nd[9];
-            int hub[9];
-            bool live[9];
+            // Any other row: the lane's nine arcs in three batches of three, each batch with its
+            // heads, costs and the labels of its heads in flight together; a batch in which no lane
+            // of the wave holds an arc with residual capacity costs nothing.
+            bool any9 = false;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) live[j] = rc9[j] > 0;
-            gather9(hd, live, pu, (i64)0, [&](int v) { return g.price[v]; });
-            gather9(hd, live, du, (i64)0, [&](int v) { return ld_dist(g, v); });
-            gather9(hd, live, hub, -1, [&](int v) { return g.hub_of[v]; });
+            for (int j = 0; j < 9; ++j) any9 |= rc9[j] > 0;
+            if (!any9) t.c[kTallyGuSkips] += mine;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) if (!live[j]) hub[j] = -1;
-            // Parallel arcs (a run of equal heads among a lane's 8 consecutive arcs) offer the same
-            // vertex; the arc length falls as the cost grows, so only the dearest live arc of a run
-            // matters: reduce the costs in 32 bits and do the 64-bit length arithmetic once per run,
-            // at its last arc.
-            int run_cost = INT32_MIN;
+            for (int b = 0; b < 3; ++b) {
+                bool live[3];
+                unsigned arc[3];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const bool cont = j > 0 && j < 8 && hd[j] == hd[j > 0 ? j - 1 : 0];
-                if (!cont) run_cost = INT32_MIN;
-                if (live[j] && cs[j] > run_cost) run_cost = cs[j];
-                const bool last = j >= 7 || hd[j < 8 ? j + 1 : 8] != hd[j];
-                nd[j] = kDistInf;
-                if (last && run_cost != INT32_MIN) {  // some arc of the run is live: pu/du/hub[j] hold the head's values
-                    const i64 l = arc_len(-(i64)run_cost * S + pu[j] - pv, sh);
-                    if (dv + l < du[j]) nd[j] = dv + l;
+                for (int j = 0; j < 3; ++j) { live[j] = rc9[3 * b + j] > 0; arc[j] = arc9(a0, at, 3 * b + j); }
+                if (!__ballot(live[0] || live[1] || live[2])) continue;
+                int hd3[3], cs3[3], hub3[3];
+                i64 nd3[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { hd3[j] = g.head[live[j] ? arc[j] : h]; cs3[j] = g.cost[live[j] ? arc[j] : h]; }
+                i64 pu[3], du[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    pu[j] = ld_sel(live[j], &g.price[hd3[j]], g.spare);
+                    du[j] = dist_of(ld_sel(live[j], &g.dist[hd3[j]], g.spare));
+                    hub3[j] = ld_sel(live[j], &g.hub_of[hd3[j]], g.spare);
                 }
-                if (!(last && run_cost != INT32_MIN)) hub[j] = -1;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    nd3[j] = kDistInf;
+                    if (!live[j]) hub3[j] = -1;
+                    if (live[j]) { const i64 l = arc_len(-(i64)cs3[j] * S + pu[j] - pv, sh); if (dv + l < du[j]) nd3[j] = dv + l; }
+                }
+                GU_COMMIT(3, g, q, dcnt, dlow, dseg, s_hmin, hd3, hub3, nd3, stamp, rot, wmax, t);
             }
-            gu_commit_batch<9>(g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
         }
     }
     const int2 *lowl = g.fr_low[src];
     const unsigned nlow_round = (nlow + 63) & ~63u;
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow_round; i += gridDim.x * kBlock) {
+    for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < nlow_round; i += gridDim.x * BLOCK) {
         const bool have = i < nlow;
         const int2 it = have ? lowl[i] : make_int2(0, 0);
         const int v = it.x & 0x0FFFFFFF;
         const unsigned deg = have ? (unsigned)it.x >> 28 : 0u, r0 = (unsigned)it.y;
-        const i64 dv = have ? dist_of(g.dist[v]) : 0, pv = have ? g.price[v] : 0;
+        const i64 dv = dist_of(g.dist[v]), pv = g.price[v];  // v = 0 for the padding lanes
         int rc4[kLowMax], hd[kLowMax], cs[kLowMax], hub[kLowMax];
         i64 pu[kLowMax], du[kLowMax], nd[kLowMax];
 #pragma unroll
-        for (unsigned j = 0; j < kLowMax; ++j) {
+        for (unsigned j = 0; j < kLowMax; ++j) {  // entries past the row's end are read (the arrays have spare entries) and dropped
             const bool ok = j < deg;
-            rc4[j] = ok ? g.rcap[r0 + j] : 0; hd[j] = ok ? g.head[r0 + j] : 0; cs[j] = ok ? g.cost[r0 + j] : 0;
+            const int rcj = g.rcap[r0 + j], hdj = g.head[r0 + j], csj = g.cost[r0 + j];
+            rc4[j] = GU_RCMASK(ok ? rcj : 0); hd[j] = ok ? hdj : 0; cs[j] = ok ? csj : 0;
         }
         t.c[kTallyGuScans] += deg;
 #pragma unroll
         for (unsigned j = 0; j < kLowMax; ++j) {
             const bool ok = rc4[j] > 0;
-            pu[j] = ok ? g.price[hd[j]] : 0; du[j] = ok ? ld_dist(g, hd[j]) : 0; hub[j] = ok ? g.hub_of[hd[j]] : -1;
+            pu[j] = ld_sel(ok, &g.price[hd[j]], g.spare); du[j] = dist_of(ld_sel(ok, &g.dist[hd[j]], g.spare));
+            const int hb = ld_sel(ok, &g.hub_of[hd[j]], g.spare);
+            hub[j] = ok ? hb : -1;
         }
 #pragma unroll
         for (unsigned j = 0; j < kLowMax; ++j) {
@@ -963,13 +1124,13 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                 if (dv + l < du[j]) nd[j] = dv + l;
             }
         }
-        gu_commit_batch<(int)kLowMax>(g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
+        GU_COMMIT((int)kLowMax, g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
     }
     __syncthreads();  // hub minima of the whole workgroup are in LDS
     // The end of the sweep is a handful of independent read-modify-writes (hub distance, the two
     // queue counters, the largest-distance slot, the work counters).  Their first halves are all
     // issued before any result is used, so the wave waits one round trip for them, not five.
-    const bool hub_cand = my_hub_vertex >= 0 && s_hmin[threadIdx.x] < kDistInf;
+    const bool hub_cand = V != 4 && my_hub_vertex >= 0 && s_hmin[threadIdx.x] < kDistInf;
     const i64 hub_nd = hub_cand ? s_hmin[threadIdx.x] : kDistInf;
     // one check per hub and workgroup, against a fresh value (most workgroups arrive after
     // the first few have lowered the hub's distance and can skip the same-address atomic)
@@ -1019,7 +1180,7 @@ __device__ __forceinline__ void gu_init_body(const DevGraph &g) {
     if (!ct->gu_init_on) return;
     __shared__ AppendLds s_app;
     const unsigned rot = mix32(ct->epoch, 0x5EEDu);
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < kGrid * (kBlock / 64); i += gridDim.x * kBlock) g.dmax_part[i] = 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < kSweepWaves; i += gridDim.x * kBlock) g.dmax_part[i] = 0;
     const int span = kBlock * kVpt;
     for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
         bool def[kVpt];
@@ -1050,7 +1211,11 @@ __device__ __forceinline__ void gu_apply_body(const DevGraph &g, int n_iters) {
     bool apply = false, rounds = true, give_up = false;
     if (ct->gu_on) {
         const unsigned *c = ct->fr_cnt[n_iters % 3];
-        if (c[kClsLow] + c[kClsSeg] == 0) apply = true;
+        const int phase = ct->gu_phase[n_iters & 1];
+        const bool dry = c[kClsLow] + c[kClsSeg] == 0;
+        // converged: seen by an expansion already, or the last one was a pull sweep that queued
+        // nothing (or found the frontier dry with no pull vertices to ask)
+        if (phase == 2 || (dry && (phase == 1 || *g.pull_cnt == 0))) apply = true;
         // the 16-bit sweep stamps are about to repeat: give this update up (leaving the prices
         // alone is always valid) and go on with push/relabel rounds
         else if (ct->gu_stamp_base + 2u * kGuIters > 60000u) give_up = true;
@@ -1065,7 +1230,7 @@ __device__ __forceinline__ void gu_apply_body(const DevGraph &g, int n_iters) {
     const i64 eps = ct->eps;
     __shared__ i64 s_dmax[kBlock / 64];
     i64 dm = 0;
-    for (int i = threadIdx.x; i < kGrid * (kBlock / 64); i += kBlock) { const i64 x = g.dmax_part[i]; dm = x > dm ? x : dm; }
+    for (int i = threadIdx.x; i < kSweepWaves; i += kBlock) { const i64 x = g.dmax_part[i]; dm = x > dm ? x : dm; }
     dm = wave_max(dm);
     if (lane_id() == 0) s_dmax[threadIdx.x >> 6] = dm;
     __syncthreads();
@@ -1096,7 +1261,13 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
     Ctrl *ct = g.ctrl;
     if (!ct->done && !ct->error && ct->rounds_on) {  // close the rounds of the previous replay
         const unsigned *c = ct->list_cnt[n_rounds & 1];
-        if (c[kClsLow] + c[kClsSeg] == 0) {
+        const unsigned left = c[kClsLow] + c[kClsSeg];
+        // A phase other than the last one need not route its last units of excess: they join what
+        // the next phase's saturation sets free (every phase starts by restoring its own
+        // epsilon-optimality, whatever pseudoflow it is given).  The long tail of a phase - a
+        // handful of units moving one arc per round - is thereby run once, at the end of the last
+        // phase, instead of once per phase.
+        if (left == 0 || (ct->eps_shift > 0 && left <= (unsigned)ct->tail_items)) {
             if (ct->eps_shift == 0) {
                 ct->done = 1;
             } else {
@@ -1123,6 +1294,7 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
             ct->gu_init_on = 1;
             ct->tally_gus++;
             for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) ct->fr_cnt[i][j] = 0;
+            ct->gu_phase[0] = ct->gu_phase[1] = 0;
             ct->gu_stamp_base = 0;
         } else {
             ct->gu_stamp_base += kGuIters;  // sweep stamps stay unique within one update
@@ -1451,6 +1623,26 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact_group(const DevGraph
 __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) { saturate_body(g); }
 __global__ __launch_bounds__(kBlock) void k_saturate_group(const DevGraph *__restrict__ gs) { saturate_body(gs[blockIdx.y]); }
 __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) { gu_expand_body(g, k); }
+#ifdef PSN_UBENCH
+template <int V>
+__global__ __launch_bounds__(kBlock, 4) void k_ub_expand(DevGraph g, int k) { gu_expand_body<V>(g, k); }
+template <int V>
+__global__ __launch_bounds__(kBlock, 3) void k_ub_expand3(DevGraph g, int k) { gu_expand_body<V>(g, k); }
+template <int V>
+__global__ __launch_bounds__(1024) void k_ub_expand_wide(DevGraph g, int k) { gu_expand_body<V, 1024, 128>(g, k); }
+__global__ void k_ub_seed(DevGraph g, int sink, int eps_shift) {
+    Ctrl *ct = g.ctrl;
+    ct->done = ct->error = 0;
+    ct->gu_on = ct->gu_init_on = ct->gu_active = 1;
+    ct->gu_stamp_base = 0;
+    ct->eps_shift = eps_shift;
+    ct->eps = (i64)1 << eps_shift;
+    ct->epoch++;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) ct->fr_cnt[i][j] = 0;
+    ct->gu_phase[0] = ct->gu_phase[1] = 0;
+    g.excess[sink] = -1;
+}
+#endif
 __global__ __launch_bounds__(kBlock, 4) void k_gu_expand_group(const DevGraph *__restrict__ gs, int k) { gu_expand_body(gs[blockIdx.y], k); }
 __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) { gu_init_body(g); }
 __global__ __launch_bounds__(kBlock) void k_gu_init_group(const DevGraph *__restrict__ gs) { gu_init_body(gs[blockIdx.y]); }

@@ -16,7 +16,7 @@ if sys.argv[1] == "run":
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     import ctypes as C
     import poseidon_amd as pa
-    cl = pa.synth_cluster(2, 1)
+    cl = pa.synth_cluster(int(os.environ.get("PSN_TC_CONFIG", "2")), 1)
     net = pa.build_network(cl)
     with pa.Solver() as s:
         s.upload(net); s.eval_costs(cl, net)
@@ -38,10 +38,10 @@ else:
         elif "k_gu_expand" in nm: kind, k = 2, ek; ek = (ek + 1) % 12
         else: continue
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        if ti < len(tr) and tr[ti][0] == kind and tr[ti][1] == k: out.append((kind, int(tr[ti][2]), int(tr[ti][3]), dur)); ti += 1
+        if ti < len(tr) and (tr[ti][0] == kind or (kind == 2 and tr[ti][0] == 3)) and tr[ti][1] == k: out.append((kind, int(tr[ti][2]), int(tr[ti][3]), dur)); ti += 1
         else: out.append((kind, 0, 0, dur))
     print("matched", ti, "of", len(tr))
-    edges = [0, 1, 64, 1024, 4096, 16384, 1 << 30]
+    edges = [0, 1, 16, 64, 256, 1024, 4096, 16384, 1 << 30]
     for kind, name in ((1, "push"), (2, "gu_expand")):
         print(name, " rows: lane items, cols: wave items", edges[1:])
         x = [o for o in out if o[0] == kind]
