@@ -460,6 +460,7 @@ int psn_create(const psn_config *cfg, psn_ctx **out) {
     if (cfg) c->cfg = *cfg;
     if (c->cfg.alpha_log2 <= 0 || c->cfg.alpha_log2 > 8) c->cfg.alpha_log2 = 4;
     c->rounds = c->cfg.rounds_per_batch > 0 ? c->cfg.rounds_per_batch : 12;
+    if (const char *ev = std::getenv("PSN_ROUNDS")) c->rounds = std::max(1, std::min(64, atoi(ev)));  // tuning aid
     if (c->rounds & 1) ++c->rounds;  // list parity must be the same at every replay start
     if (c->rounds > 62) c->rounds = 62;
     c->device = c->cfg.device;

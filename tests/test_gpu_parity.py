@@ -427,3 +427,82 @@ def test_network_built_on_the_device_equals_the_host_builder(cfg, seed):
         with pytest.raises(pa.PsnError) as ei:
             s.build_network(bad)
         assert ei.value.code == _lib.PSN_EINVAL
+
+
+@pytest.mark.parametrize("div", ["1", "3", "16"])
+def test_phases_cut_short_still_end_at_the_optimum(solver, monkeypatch, div):
+    """Phases other than the last may stop with a few items of excess still active (by default
+    1/128 of the vertices with supply; here far more, so that small networks exercise it): the
+    leftovers are routed by the later phases and the result is the same optimum, certified."""
+    monkeypatch.setenv("PSN_TAIL_DIV", div)
+    rng = np.random.default_rng(int(div))
+    for trial in range(12):
+        n = int(rng.integers(20, 300))
+        g = random_graph(rng, n, int(rng.integers(2 * n, 10 * n)), maxcap=int(rng.choice([1, 5, 50])), maxcost=2000, neg=trial % 3 == 0)
+        r = solve_and_certify(solver, g)
+        rc, tc, _, _ = capi.ssp(g)
+        assert rc == 0 and tc == r.total_cost, (trial, tc, r.total_cost)
+    e = _gold(0, 1)
+    cl = pa.synth_cluster(0, 1)
+    net = pa.build_network(cl)
+    solver.upload(net)
+    solver.eval_costs(cl, net)
+    r = solver.solve()
+    assert r.total_cost == e["optimal_cost"]
+    og = synth.build_graph(synth.make_cluster(0, 1))
+    assert capi.check(og, solver.residual(), solver.prices(), scale=solver.price_scale())[:2] == (0, r.total_cost)
+
+
+def test_leaf_vertices_that_fetch_their_own_distance(solver):
+    """Vertices of degree <= 4 whose neighbours all have a larger degree are left out of the
+    frontier expansions of a price update and work their distance out themselves when the frontier
+    runs dry.  Transportation networks whose many small sources AND many small sinks are such
+    leaves around a few large transit vertices, with every route through a transit vertex and some
+    routes through another leaf's transit neighbour only: optimum and certificate as for any graph."""
+    rng = np.random.default_rng(77)
+    for trial in range(10):
+        n_mid = int(rng.integers(2, 6))
+        n_src = int(rng.integers(20, 200))
+        n_dst = int(rng.integers(20, 200))
+        n = n_mid + n_src + n_dst
+        tail, head, cap, cost = [], [], [], []
+        for s_ in range(n_src):  # 1..3 arcs from each source leaf to transit vertices
+            for m_ in rng.choice(n_mid, size=int(rng.integers(1, min(3, n_mid) + 1)), replace=False):
+                tail.append(n_mid + s_); head.append(int(m_)); cap.append(int(rng.integers(1, 4))); cost.append(int(rng.integers(0, 500)))
+        for d_ in range(n_dst):  # and from transit vertices to each sink leaf
+            for m_ in rng.choice(n_mid, size=int(rng.integers(1, min(3, n_mid) + 1)), replace=False):
+                tail.append(int(m_)); head.append(n_mid + n_src + d_); cap.append(int(rng.integers(1, 4))); cost.append(int(rng.integers(0, 500)))
+        for a in range(n_mid):  # transit vertices among themselves
+            for b in range(n_mid):
+                if a != b:
+                    tail.append(a); head.append(b); cap.append(1000); cost.append(int(rng.integers(1, 300)))
+        tail, head, cap, cost = (np.asarray(x, np.int64) for x in (tail, head, cap, cost))
+        # supplies from a random feasible flow: source -> transit -> sink paths
+        supply = np.zeros(n, np.int64)
+        out_cap = np.zeros(n, np.int64); in_cap = np.zeros(n, np.int64)
+        np.add.at(out_cap, tail[tail >= n_mid], cap[tail >= n_mid])
+        np.add.at(in_cap, head[head >= n_mid + n_src], cap[head >= n_mid + n_src])
+        units = int(min(out_cap.sum(), in_cap.sum()) // 3)
+        f = np.zeros(len(cap), np.int64)
+        # greedy: fill source arcs and sink arcs up to `units` each, transit arcs carry the imbalance
+        left = units
+        for a in np.flatnonzero(tail >= n_mid):
+            x = min(int(cap[a]), left); f[a] = x; left -= x
+        left = units
+        for a in np.flatnonzero(head >= n_mid + n_src):
+            x = min(int(cap[a]), left); f[a] = x; left -= x
+        np.add.at(supply, tail, f); np.add.at(supply, head, -f)
+        # transit vertices are left unbalanced by the two greedy fills: move the difference to transit 0
+        # over the transit arcs (capacity 1000 each, plenty)
+        for m_ in range(1, n_mid):
+            if supply[m_] != 0:
+                supply[0] += supply[m_]; supply[m_] = 0
+        g = synth.graph_from_arcs(n, tail, head, cap, cost, supply)
+        rc, tc, _, _ = capi.ssp(g)
+        solver.upload_csr(g.n, g.row_off, g.head, g.cap, g.cost, g.rev, g.supply)
+        if rc != 0:
+            with pytest.raises(pa.PsnError):
+                solver.solve()
+            continue
+        r = solve_and_certify(solver, g)
+        assert tc == r.total_cost, (trial, tc, r.total_cost)
