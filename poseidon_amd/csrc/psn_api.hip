@@ -1100,6 +1100,11 @@ static int solve_start(psn_ctx *c, hipStream_t s, bool warm, const i64 *h_scalar
     if (const char *ev = std::getenv("PSN_TAIL_DIV")) tail_div = std::max(1, atoi(ev));
     init.tail_items = (int)std::min<i64>(1 << 20, h_scalar[kSourcesSlot] / tail_div);
     if (const char *ev = std::getenv("PSN_TAIL_ITEMS")) init.tail_items = std::max(0, atoi(ev));
+    // ... or when no more than a couple of dozen vertices are active, whatever their size (a task class
+    // alone is some 90 work items: a network with few sources never gets down to few items)
+    init.tail_vertices = (int)std::min<i64>(kTailVertices, h_scalar[kSourcesSlot] / 32);
+    if (const char *ev = std::getenv("PSN_TAIL_VERTICES")) init.tail_vertices = std::max(0, atoi(ev));
+    if (std::getenv("PSN_TAIL_DIV") || std::getenv("PSN_TAIL_ITEMS")) init.tail_vertices = std::min(init.tail_vertices, init.tail_items);
     int shift0;
     if (!warm) {
         // Zero flow with zero prices is 0-optimal when no usable arc has a negative cost, so the

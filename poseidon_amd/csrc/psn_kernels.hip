@@ -551,11 +551,13 @@ __device__ __forceinline__ HubTurn hub_fetch(const DevGraph &g, int hv) {
     h.r0 = g.row[hv]; h.r1 = g.row[hv + 1]; h.seg1 = g.seg1_of[hv];
     return h;
 }
-__device__ __forceinline__ void hub_decide(const DevGraph &g, HubTurn &h, bool do_relabel, i64 eps, unsigned rot, Tally &t) {
+constexpr int kCntVertices = 3;  // work-list counter slot: active vertices (a split vertex counts once, whatever its items)
+__device__ __forceinline__ void hub_decide(const DevGraph &g, HubTurn &h, bool do_relabel, i64 eps, unsigned rot, Tally &t, unsigned *cnt) {
     h.act = h.e > 0;
     h.nseg = (h.r1 - h.r0 + kWSeg - 1) / kWSeg;
     h.first = (rot ^ (unsigned)h.v * 0x9E3779B9u) % h.nseg;
     if (threadIdx.x == 0) {
+        if (h.act) __hip_atomic_fetch_add(&cnt[kCntVertices], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (h.act && do_relabel && h.c != kInf && h.c != kNegInf && h.c <= h.p) { g.price[h.v] = h.c - eps; t.c[kTallyRelabels]++; }
         const i64 nc = h.act ? kNegInf : kInf;
         if (h.c != nc) g.cand[h.v] = nc;
@@ -613,7 +615,7 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
         if (base != (int)blockIdx.x * span) fetch(base);
         bool act[kVpt];
         unsigned hub_segs = 0, hub_base = 0;  // the hub's slots ride on the sweep's own slot atomic
-        if (hub_state == 1) { hub_decide(g, hub, do_relabel, eps, rot, t); hub_segs = hub.act ? hub.nseg : 0u; }
+        if (hub_state == 1) { hub_decide(g, hub, do_relabel, eps, rot, t, ct->list_cnt[dst]); hub_segs = hub.act ? hub.nseg : 0u; }
 #pragma unroll
         for (int i = 0; i < kVpt; ++i) {
             act[i] = e[i] > 0 && seg1[i] == 0;  // not a hub (and inside the vertex range)
@@ -625,6 +627,13 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
             const i64 nc = act[i] ? kNegInf : kInf;
             if (seg1[i] == 0 && c[i] != nc) g.cand[v[i]] = nc;
         }
+        {
+            unsigned nact = 0;
+#pragma unroll
+            for (int i = 0; i < kVpt; ++i) nact += act[i];
+            nact = wave_sum_u32(nact);
+            if (lane_id() == 0 && nact) __hip_atomic_fetch_add(&ct->list_cnt[dst][kCntVertices], nact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app, hub_segs, &hub_base);
         if (hub_state == 1) { if (hub.act) append_hub(hub, hub_base, g.list_seg[dst]); hub_state = 2; }
     }
@@ -632,7 +641,7 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
     for (int hs = (int)blockIdx.x; hs < g.nhubs; hs += (int)gridDim.x) {
         if (hs == (int)blockIdx.x && hub_state == 2) continue;
         if (hs != (int)blockIdx.x) hub = hub_fetch(g, g.hub_vertex[hs]);
-        hub_decide(g, hub, do_relabel, eps, rot, t);
+        hub_decide(g, hub, do_relabel, eps, rot, t, ct->list_cnt[dst]);
         if (hub.act) {  // workgroup-uniform
             if (threadIdx.x == 0) s_hub_base = aadd32(&ct->list_cnt[dst][kClsSeg], hub.nseg);
             __syncthreads();
@@ -1266,8 +1275,10 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
         // the next phase's saturation sets free (every phase starts by restoring its own
         // epsilon-optimality, whatever pseudoflow it is given).  The long tail of a phase - a
         // handful of units moving one arc per round - is thereby run once, at the end of the last
-        // phase, instead of once per phase.
-        if (left == 0 || (ct->eps_shift > 0 && left <= (unsigned)ct->tail_items)) {
+        // phase, instead of once per phase.  "Little left" is few work items, or few active vertices
+        // (a task class alone is some 90 items: a network with few sources and large vertices never
+        // gets down to few items).
+        if (left == 0 || (ct->eps_shift > 0 && (left <= (unsigned)ct->tail_items || c[kCntVertices] <= (unsigned)ct->tail_vertices))) {
             if (ct->eps_shift == 0) {
                 ct->done = 1;
             } else {
