@@ -91,3 +91,57 @@ def test_single_rank_passthrough():
     local = torch.arange(12, dtype=torch.int32).view(3, 4)
     assert torch.equal(batch.all_gather_placements(local, 3, 1, 0), local)
     assert batch.all_gather_costs([5, 6, 7], 3, 1, 0) == [5, 6, 7]
+
+
+def _gpu_worker(rank, world, port, n_graphs, q):
+    """One rank of the N > 1 path with the product solver: its shard of the batch resident in its own
+    solver contexts (both ranks share GPU 0 here), solved with psn_solve_batch, placements extracted
+    on the device, gathered over the process group in graph order."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import poseidon_amd as pa
+    from poseidon_amd import batch
+    mine = batch.shard(n_graphs, world, rank)
+    solvers, clusters = [], []
+    for b in mine:
+        cl = pa.synth_cluster(0, 1 + b, 12 + b, 60)
+        s = pa.Solver(device=0)
+        net = s.build_network(cl)
+        s.eval_costs(cl, net)
+        solvers.append(s); clusters.append(cl)
+    res = batch.solve_batch(solvers)
+    rows = [s.placements() for s in solvers]
+    local = torch.from_numpy(np.stack(rows)) if rows else torch.empty((0, 60), dtype=torch.int32)
+    allp = batch.all_gather_placements(local, n_graphs, world, rank)
+    allc = batch.all_gather_costs([r.total_cost for r in res], n_graphs, world, rank)
+    for s in solvers:
+        s.close()
+    if rank == 0:
+        q.put((allp.numpy(), allc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_solve_their_shards_on_the_gpu_and_gather():
+    from oracle import capi, synth
+    n_graphs = 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, n_graphs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    allp, allc = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for b in range(n_graphs):
+        cl = synth.make_cluster(0, 1 + b, 12 + b, 60)
+        g = synth.build_graph(cl)
+        rc, tc, _, _, _ = capi.cost_scaling(g)
+        assert rc == 0 and allc[b] == tc, (b, allc[b], tc)
+        # the placements reproduce the objective: every placed task pays its class's slot costs on its machine
+        p = allp[b]
+        assert p.shape[0] == 60 and int((p >= 0).sum()) > 0 and int(p.max()) < 12 + b
