@@ -1740,36 +1740,36 @@ int psn_placements_device_ptr(psn_ctx *c, void **dptr, int64_t *count) {
 }
 
 #ifdef PSN_UBENCH
-// Development builds only: time expansion-sweep variants on the state a finished solve left.
-// For every target iteration kt in [1, max_kt]: seed the sink as the only deficit, run the
-// shipping sweep for iterations 0..kt-1 and the variant at kt.  Read the durations from a
-// kernel trace.  The context's solution is destroyed.
-int psn_debug_gu_bench(psn_ctx *c, int variant, int reps, int eps_shift, int sink, int max_kt) {
+// Development builds only (-DPSN_UBENCH): the frontier expansions of one global update, seeded at
+// `sink`, on the state a finished solve left, `reps` times over - one launch per expansion, to be
+// timed expansion by expansion from a kernel trace (tools/ubench/gu_bench.py).  The context's
+// solution is destroyed.
+namespace psn {
+__global__ void k_ub_seed(DevGraph g, int sink, int eps_shift) {
+    Ctrl *ct = g.ctrl;
+    ct->done = ct->error = 0;
+    ct->gu_on = ct->gu_init_on = ct->gu_active = 1;
+    ct->gu_stamp_base = 0;
+    ct->eps_shift = eps_shift;
+    ct->eps = (i64)1 << eps_shift;
+    ct->epoch++;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) ct->fr_cnt[i][j] = 0;
+    ct->gu_phase[0] = ct->gu_phase[1] = 0;
+    g.excess[sink] = -1;
+}
+}  // namespace psn
+int psn_debug_gu_bench(psn_ctx *c, int reps, int eps_shift, int sink, int n_expansions) {
     if (!c || !c->uploaded) return PSN_ESTATE;
     HIPCHK(c, hipSetDevice(c->device));
     const DevGraph &g = c->g;
     const int gv = std::max(1, std::min(kGrid, (g.n + kBlock * kVpt - 1) / (kBlock * kVpt)));
     const int gs = (int)std::max<long long>(32, std::min<long long>(kGrid, (c->m2 + kBlock * 16 - 1) / (kBlock * 16)));
     hipStream_t s = c->stream;
-    for (int r = 0; r < reps; ++r)
-        for (int kt = 1; kt <= max_kt; ++kt) {
-            hipLaunchKernelGGL(k_ub_seed, dim3(1), dim3(1), 0, s, g, sink, eps_shift);
-            hipLaunchKernelGGL(k_gu_init, dim3(gv), dim3(kBlock), 0, s, g);
-            for (int k = 0; k < kt; ++k) hipLaunchKernelGGL(k_gu_expand, dim3(gs), dim3(kBlock), 0, s, g, k);
-            switch (variant) {
-            case 0: hipLaunchKernelGGL(k_ub_expand<0>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
-            case 1: hipLaunchKernelGGL(k_ub_expand<1>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
-            case 2: hipLaunchKernelGGL(k_ub_expand<2>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
-            case 4: hipLaunchKernelGGL(k_ub_expand<4>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
-            case 5: hipLaunchKernelGGL(k_ub_expand<5>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
-            case 7: hipLaunchKernelGGL(k_ub_expand3<7>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
-            case 8: hipLaunchKernelGGL(k_ub_expand3<8>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
-            case 9: hipLaunchKernelGGL(k_ub_expand3<1>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
-            case 6: hipLaunchKernelGGL(k_ub_expand<6>, dim3(gs), dim3(kBlock), 0, s, g, kt); break;
-            case 3: hipLaunchKernelGGL(k_ub_expand_wide<3>, dim3(gs / 4), dim3(1024), 0, s, g, kt); break;
-            default: return PSN_EINVAL;
-            }
-        }
+    for (int r = 0; r < reps; ++r) {
+        hipLaunchKernelGGL(psn::k_ub_seed, dim3(1), dim3(1), 0, s, g, sink, eps_shift);
+        hipLaunchKernelGGL(k_gu_init, dim3(gv), dim3(kBlock), 0, s, g);
+        for (int k = 0; k < n_expansions; ++k) hipLaunchKernelGGL(k_gu_expand, dim3(gs), dim3(kBlock), 0, s, g, k);
+    }
     HIPCHK(c, hipStreamSynchronize(s));
     return PSN_OK;
 }

@@ -459,7 +459,9 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
                     for (int x = 0; x < W; ++x) {  // rcap mirrors cap[rev]: no dependent load for the reverse capacity
                         const int j = b0 + x < 9 ? b0 + x : 8;
                         const bool on = d[x] > 0;
-                        rv[x] = on ? g.rev[arc9(a0, at, j)] : 0; hub[x] = on ? g.hub_of[hd[j]] : -1; cr[x] = on ? g.rcap[arc9(a0, at, j)] : 0;
+                        const unsigned ax = on ? arc9(a0, at, j) : h;  // no control flow around the loads (see ld_sel)
+                        const int rvx = g.rev[ax], crx = g.rcap[ax], hbx = ld_sel(on, &g.hub_of[hd[j]], g.spare);
+                        rv[x] = on ? rvx : 0; hub[x] = on ? hbx : -1; cr[x] = on ? crx : 0;
                     }
 #pragma unroll
                     for (int x = 0; x < W; ++x) {
@@ -525,8 +527,10 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
     const int my_hub_vertex = hub_vertex_of_thread(g);
+    int4 it_next = wave < nseg ? segl[wave] : make_int4(0, 0, 0, 0);
     for (unsigned i = wave; i < nseg; i += nwaves) {
-        const int4 it = segl[i];
+        const int4 it = it_next;
+        if (i + nwaves < nseg) it_next = segl[i + nwaves];  // on its way while this item is worked on
         push_item(g, hb, it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t);
     }
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, hb, lowl[i], S, k & 1, t);
@@ -759,7 +763,7 @@ __device__ __forceinline__ i64 opaque(i64 x) { asm("" : "+v"(x)); return x; }
 // issued together, before any result is used: a lane pays one round trip per step for the
 // commit, not one per arc and not a second one for the lookups.
 // Hubs (hub[j] >= 0) are only lowered in LDS here; the workgroup commits them at the end.
-template <int NJ, unsigned QC = kQCap>
+template <int NJ>
 __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, unsigned *dcnt, int2 *dlow, int4 *dseg, i64 *hub_min,
                                                 const int (&hd)[NJ], const int (&hub)[NJ], const i64 (&nd)[NJ], unsigned stamp,
                                                 unsigned rot, i64 &wmax, Tally &t) {
@@ -805,8 +809,8 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
     if (__ballot(nl != 0)) {
         const unsigned incl = wave_incl_scan_u32(nl);
         const unsigned tot = __shfl(incl, 63);
-        if (q.nlow + tot > QC) waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
-        if (tot > QC) {  // more than the staging queue holds: straight to memory
+        if (q.nlow + tot > kQCap) waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
+        if (tot > kQCap) {  // more than the staging queue holds: straight to memory
             unsigned base = 0;
             if (lane_id() == 0) base = aadd32(&dcnt[kClsLow], tot);
             unsigned pos = __shfl(base, 0) + incl - nl;
@@ -822,8 +826,8 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
     if (__ballot(ns != 0)) {
         const unsigned incl = wave_incl_scan_u32(ns);
         const unsigned tot = __shfl(incl, 63);
-        if (q.nseg + tot > QC) waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);
-        if (tot > QC) {
+        if (q.nseg + tot > kQCap) waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);
+        if (tot > kQCap) {
             unsigned base = 0;
             if (lane_id() == 0) base = aadd32(&dcnt[kClsSeg], tot);
             unsigned pos = __shfl(base, 0) + incl - ns;
@@ -840,41 +844,6 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
     for (int j = 0; j < NJ; ++j) if (cls[j] == kClsHigh) append_split(dcnt, dseg, hd[j], r0[j], r1[j], rot ^ (unsigned)hd[j]);
 }
 
-#ifdef PSN_UBENCH
-// Timing probes of the expansion sweep (development builds only): V = 1 drops the commit of the
-// candidates, V = 2 treats every arc as having no residual capacity after loading it.
-template <int V, int NJ, unsigned QC>
-__device__ __forceinline__ void gu_commit_probe(const DevGraph &g, WaveQ &q, unsigned *dcnt, int2 *dlow, int4 *dseg, i64 *hub_min,
-                                                const int (&hd)[NJ], const int (&hub)[NJ], const i64 (&nd)[NJ], unsigned stamp,
-                                                unsigned rot, i64 &wmax, Tally &t) {
-    if constexpr (V == 1) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) if (nd[j] < kDistInf && nd[j] + hd[j] + hub[j] > wmax) wmax = nd[j];
-    } else if constexpr (V == 8) {
-        if (g.n < 0) gu_commit_batch<NJ, QC>(g, q, dcnt, dlow, dseg, hub_min, hd, hub, nd, stamp, rot, wmax, t);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) if (nd[j] < kDistInf && nd[j] + hd[j] + hub[j] > wmax) wmax = nd[j];
-    } else if constexpr (V == 6) {  // no relaxation of the task vertices of the 10 000-machine synthetic cluster
-        i64 nd2[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) nd2[j] = hd[j] >= 11665 ? kDistInf : nd[j];
-        gu_commit_batch<NJ, QC>(g, q, dcnt, dlow, dseg, hub_min, hd, hub, nd2, stamp, rot, wmax, t);
-    } else if constexpr (V == 5) {
-        i64 nd2[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) nd2[j] = hub[j] >= 0 ? kDistInf : nd[j];
-        gu_commit_batch<NJ, QC>(g, q, dcnt, dlow, dseg, hub_min, hd, hub, nd2, stamp, rot, wmax, t);
-    } else {
-        gu_commit_batch<NJ, QC>(g, q, dcnt, dlow, dseg, hub_min, hd, hub, nd, stamp, rot, wmax, t);
-    }
-}
-#define GU_COMMIT(NJ, ...) gu_commit_probe<V, NJ, QC>(__VA_ARGS__)
-#define GU_RCMASK(x) ((V == 2) ? ((x) & rc_zero) : (x))
-#else
-#define GU_COMMIT(NJ, ...) gu_commit_batch<NJ, QC>(__VA_ARGS__)
-#define GU_RCMASK(x) (x)
-#endif
-template <int V = 0, int BLOCK = kBlock, unsigned QC = kQCap>
 __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_on) return;
@@ -896,28 +865,25 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
         const unsigned i = aadd32(g.dbg_cnt, 1u);
         if (i < kDbgCap) g.dbg[i] = do_pull ? make_int4(3, k, (int)npull, 0) : make_int4(2, k, (int)nlow, (int)nseg);
     }
-    __shared__ int2 lds_low[(BLOCK / 64) * QC];
-    __shared__ int4 lds_seg[(BLOCK / 64) * QC];
+    __shared__ int2 lds_low[(kBlock / 64) * kQCap];
+    __shared__ int4 lds_seg[(kBlock / 64) * kQCap];
     __shared__ i64 s_hmin[kMaxHubs];
-    for (int i = threadIdx.x; i < kMaxHubs; i += BLOCK) s_hmin[i] = kDistInf;
+    for (int i = threadIdx.x; i < kMaxHubs; i += kBlock) s_hmin[i] = kDistInf;
     __syncthreads();
     WaveQ q;
-    q.low = lds_low + (threadIdx.x >> 6) * QC;
-    q.seg = lds_seg + (threadIdx.x >> 6) * QC;
+    q.low = lds_low + (threadIdx.x >> 6) * kQCap;
+    q.seg = lds_seg + (threadIdx.x >> 6) * kQCap;
     q.nlow = q.nseg = 0;
     unsigned *dcnt = ct->fr_cnt[dst];
     int2 *dlow = g.fr_low[dst];
     int4 *dseg = g.fr_seg[dst];
     const i64 S = g.scale;
     const int sh = ct->eps_shift;
-#ifdef PSN_UBENCH
-    const int rc_zero = g.n > 0 ? 0 : -1;
-#endif
     const unsigned stamp = (ct->gu_stamp_base + (unsigned)k) % 65535u + 1u;  // 16 bits, never 0
     const unsigned rot = mix32(ct->epoch, stamp);
     const int lane = lane_id();
-    const unsigned wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    const unsigned nwaves = (gridDim.x * BLOCK) >> 6;
+    const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const unsigned nwaves = (gridDim.x * kBlock) >> 6;
     Tally t;
     const int my_hub_vertex = hub_vertex_of_thread(g);
     i64 wmax = 0;
@@ -925,7 +891,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     if (do_pull) {
         const int2 *pl = g.pull_list;
         const unsigned np_round = (npull + 63) & ~63u;
-        for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < np_round; i += gridDim.x * BLOCK) {
+        for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < np_round; i += gridDim.x * kBlock) {
             const bool have = i < npull;
             const int2 it = pl[have ? i : 0];
             const int v = it.x & 0x0FFFFFFF;
@@ -937,7 +903,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
             for (unsigned j = 0; j < kLowMax; ++j) {  // entries past the row's end are read (the arrays have spare entries) and dropped
                 const bool ok = j < deg;
                 const int rcj = g.rcap[r0 + j], cpj = g.cap[r0 + j], hdj = g.head[r0 + j], csj = g.cost[r0 + j];
-                rc4[j] = GU_RCMASK(ok ? rcj : 0); cp4[j] = ok ? cpj : 0; hd[j] = ok ? hdj : 0; cs[j] = ok ? csj : 0;
+                rc4[j] = ok ? rcj : 0; cp4[j] = ok ? cpj : 0; hd[j] = ok ? hdj : 0; cs[j] = ok ? csj : 0;
             }
             t.c[kTallyGuScans] += deg;
 #pragma unroll
@@ -972,7 +938,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                     if (best + l < du[j]) nd[j] = best + l;
                 }
             }
-            GU_COMMIT((int)kLowMax, g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
+            gu_commit_batch<(int)kLowMax>(g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
         }
     }
     const int4 *segl = g.fr_seg[src];
@@ -997,7 +963,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
             const bool in = a < r1;
             const unsigned ac = in ? a : r0;
             const int rc_raw = g.rcap[ac], hd_raw = g.head[ac], cs_raw = g.cost[ac];
-            const int rc = GU_RCMASK(in ? rc_raw : 0);
+            const int rc = in ? rc_raw : 0;
             int hd1[1] = {in ? hd_raw : 0}, hub1[1] = {-1};
             const int cs1 = in ? cs_raw : 0;
             t.c[kTallyGuScans] += in;
@@ -1007,7 +973,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
             if (on) hub1[0] = hb1;
             i64 nd1[1] = {kDistInf};
             if (on) { const i64 l = arc_len(-(i64)cs1 * S + p1 - pv, sh); if (dv + l < d1) nd1[0] = dv + l; }
-            GU_COMMIT(1, g, q, dcnt, dlow, dseg, s_hmin, hd1, hub1, nd1, stamp, rot, wmax, t);
+            gu_commit_batch<1>(g, q, dcnt, dlow, dseg, s_hmin, hd1, hub1, nd1, stamp, rot, wmax, t);
             continue;
         }
         int rc_next[9];
@@ -1016,7 +982,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
             const unsigned a0 = h + lane * 8, lim8 = min(r1, h + 512), at = h + 512 + lane, limt = min(r1, h + kStep);
             int rc9[9];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) rc9[j] = GU_RCMASK(rc_next[j]);
+            for (int j = 0; j < 9; ++j) rc9[j] = rc_next[j];
             if (h + kStep < r1) {  // the capacities of the item's next step travel while this one is worked on
                 const unsigned hn = h + kStep;
                 load9(g.rcap, hn + lane * 8, min(r1, hn + 512), hn + 512 + lane, min(r1, hn + kStep), rc_next, true, hn);
@@ -1063,7 +1029,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                 hub2[1] = on1 ? hb1 : -1;
                 if (on0) { const i64 l = arc_len(-(i64)c0 * S + p0 - pv, sh); if (dv + l < d0) nd2[0] = dv + l; }
                 if (on1) { const i64 l = arc_len(-(i64)cs[8] * S + p1 - pv, sh); if (dv + l < d1) nd2[1] = dv + l; }
-                GU_COMMIT(2, g, q, dcnt, dlow, dseg, s_hmin, hd2, hub2, nd2, stamp, rot, wmax, t);
+                gu_commit_batch<2>(g, q, dcnt, dlow, dseg, s_hmin, hd2, hub2, nd2, stamp, rot, wmax, t);
                 continue;
             }
             // Any other row: the lane's nine arcs in three batches of three, each batch with its
@@ -1097,13 +1063,13 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                     if (!live[j]) hub3[j] = -1;
                     if (live[j]) { const i64 l = arc_len(-(i64)cs3[j] * S + pu[j] - pv, sh); if (dv + l < du[j]) nd3[j] = dv + l; }
                 }
-                GU_COMMIT(3, g, q, dcnt, dlow, dseg, s_hmin, hd3, hub3, nd3, stamp, rot, wmax, t);
+                gu_commit_batch<3>(g, q, dcnt, dlow, dseg, s_hmin, hd3, hub3, nd3, stamp, rot, wmax, t);
             }
         }
     }
     const int2 *lowl = g.fr_low[src];
     const unsigned nlow_round = (nlow + 63) & ~63u;
-    for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < nlow_round; i += gridDim.x * BLOCK) {
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow_round; i += gridDim.x * kBlock) {
         const bool have = i < nlow;
         const int2 it = have ? lowl[i] : make_int2(0, 0);
         const int v = it.x & 0x0FFFFFFF;
@@ -1115,7 +1081,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
         for (unsigned j = 0; j < kLowMax; ++j) {  // entries past the row's end are read (the arrays have spare entries) and dropped
             const bool ok = j < deg;
             const int rcj = g.rcap[r0 + j], hdj = g.head[r0 + j], csj = g.cost[r0 + j];
-            rc4[j] = GU_RCMASK(ok ? rcj : 0); hd[j] = ok ? hdj : 0; cs[j] = ok ? csj : 0;
+            rc4[j] = ok ? rcj : 0; hd[j] = ok ? hdj : 0; cs[j] = ok ? csj : 0;
         }
         t.c[kTallyGuScans] += deg;
 #pragma unroll
@@ -1133,13 +1099,13 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                 if (dv + l < du[j]) nd[j] = dv + l;
             }
         }
-        GU_COMMIT((int)kLowMax, g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
+        gu_commit_batch<(int)kLowMax>(g, q, dcnt, dlow, dseg, s_hmin, hd, hub, nd, stamp, rot, wmax, t);
     }
     __syncthreads();  // hub minima of the whole workgroup are in LDS
     // The end of the sweep is a handful of independent read-modify-writes (hub distance, the two
     // queue counters, the largest-distance slot, the work counters).  Their first halves are all
     // issued before any result is used, so the wave waits one round trip for them, not five.
-    const bool hub_cand = V != 4 && my_hub_vertex >= 0 && s_hmin[threadIdx.x] < kDistInf;
+    const bool hub_cand = my_hub_vertex >= 0 && s_hmin[threadIdx.x] < kDistInf;
     const i64 hub_nd = hub_cand ? s_hmin[threadIdx.x] : kDistInf;
     // one check per hub and workgroup, against a fresh value (most workgroups arrive after
     // the first few have lowered the hub's distance and can skip the same-address atomic)
@@ -1634,26 +1600,6 @@ __global__ __launch_bounds__(kBlock) void k_relabel_compact_group(const DevGraph
 __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) { saturate_body(g); }
 __global__ __launch_bounds__(kBlock) void k_saturate_group(const DevGraph *__restrict__ gs) { saturate_body(gs[blockIdx.y]); }
 __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) { gu_expand_body(g, k); }
-#ifdef PSN_UBENCH
-template <int V>
-__global__ __launch_bounds__(kBlock, 4) void k_ub_expand(DevGraph g, int k) { gu_expand_body<V>(g, k); }
-template <int V>
-__global__ __launch_bounds__(kBlock, 3) void k_ub_expand3(DevGraph g, int k) { gu_expand_body<V>(g, k); }
-template <int V>
-__global__ __launch_bounds__(1024) void k_ub_expand_wide(DevGraph g, int k) { gu_expand_body<V, 1024, 128>(g, k); }
-__global__ void k_ub_seed(DevGraph g, int sink, int eps_shift) {
-    Ctrl *ct = g.ctrl;
-    ct->done = ct->error = 0;
-    ct->gu_on = ct->gu_init_on = ct->gu_active = 1;
-    ct->gu_stamp_base = 0;
-    ct->eps_shift = eps_shift;
-    ct->eps = (i64)1 << eps_shift;
-    ct->epoch++;
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) ct->fr_cnt[i][j] = 0;
-    ct->gu_phase[0] = ct->gu_phase[1] = 0;
-    g.excess[sink] = -1;
-}
-#endif
 __global__ __launch_bounds__(kBlock, 4) void k_gu_expand_group(const DevGraph *__restrict__ gs, int k) { gu_expand_body(gs[blockIdx.y], k); }
 __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) { gu_init_body(g); }
 __global__ __launch_bounds__(kBlock) void k_gu_init_group(const DevGraph *__restrict__ gs) { gu_init_body(gs[blockIdx.y]); }
