@@ -341,7 +341,7 @@ __global__ void k_cover_count(const unsigned char *in_cover, int n, unsigned *ou
 
 // Cost statistics of the arcs that can carry flow: out[0] = max |cost|, out[1] = number with a
 // negative cost, out[2 + b] = number with 2^(b-1) < cost <= 2^b (b = 0 holds costs 0 and 1).
-__global__ void k_cost_stats(DevGraph g, i64 *out) {
+__device__ __forceinline__ void cost_stats_body(const DevGraph &g, i64 *out) {
     __shared__ unsigned s_hist[33];
     if (threadIdx.x < 33) s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -364,7 +364,7 @@ __global__ void k_cost_stats(DevGraph g, i64 *out) {
     }
 }
 // Largest amount by which a residual arc's reduced cost is below zero (warm start).
-__global__ void k_max_violation(DevGraph g, i64 *out) {
+__device__ __forceinline__ void max_violation_body(const DevGraph &g, i64 *out) {
     i64 mx = 0;
     for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) {
         if (g.cap[a] > 0) {
@@ -378,7 +378,7 @@ __global__ void k_max_violation(DevGraph g, i64 *out) {
 
 // Sum of the supplies of the resident network (psn_update_supplies may have unbalanced them) and
 // the number of vertices that hold supply.
-__global__ void k_sum_supply(const i64 *supply, int n, i64 *out, i64 *n_sources) {
+__device__ __forceinline__ void sum_supply_body(const i64 *supply, int n, i64 *out, i64 *n_sources) {
     i64 sm = 0;
     unsigned src = 0;
     for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) { sm += supply[v]; src += supply[v] > 0; }
@@ -391,6 +391,20 @@ __global__ void k_sum_supply(const i64 *supply, int n, i64 *out, i64 *n_sources)
 constexpr int kScalarSlots = 40;
 constexpr int kSupplySumSlot = 38;  // d_scalar: [0] total cost, [1] max violation, [2..35] cost statistics, [36] vertices with supply, [38] supply sum
 constexpr int kSourcesSlot = 36;
+__global__ void k_cost_stats(DevGraph g, i64 *out) { cost_stats_body(g, out); }
+__global__ void k_max_violation(DevGraph g, i64 *out) { max_violation_body(g, out); }
+__global__ void k_sum_supply(const i64 *supply, int n, i64 *out, i64 *n_sources) { sum_supply_body(supply, n, out, n_sources); }
+// for the members of a lockstep group (blockIdx.y picks the member): the statistics the first
+// epsilon comes from - of the costs for a cold member, of the kept prices' violations for a warm one
+__global__ void k_start_stats_group(const DevGraph *__restrict__ gs, const GroupAux *__restrict__ aux) {
+    const GroupAux &x = aux[blockIdx.y];
+    if (x.warm) max_violation_body(gs[blockIdx.y], x.scalar + 1);
+    else cost_stats_body(gs[blockIdx.y], x.scalar + 2);
+}
+__global__ void k_sum_supply_group(const DevGraph *__restrict__ gs, const GroupAux *__restrict__ aux) {
+    const GroupAux &x = aux[blockIdx.y];
+    sum_supply_body(x.supply, gs[blockIdx.y].n, x.scalar + kSupplySumSlot, x.scalar + kSourcesSlot);
+}
 
 // Marks and counts the vertex cover of the resident network on the context's stream; the count is
 // on its way to h_flag[2] when this returns (d_scalar slot kCoverSlot is the device counter).
@@ -1091,7 +1105,7 @@ static int solve_prepare(psn_ctx *c, hipStream_t s, bool warm, i64 *h_scalar) {
     return PSN_OK;
 }
 // The control block a solve starts from (into the context's pinned copy) and its upload.
-static int solve_start(psn_ctx *c, hipStream_t s, bool warm, const i64 *h_scalar) {
+static Ctrl solve_init(psn_ctx *c, bool warm, const i64 *h_scalar) {
     const DevGraph &g = c->g;
     Ctrl init{};
     init.alpha_log2 = c->cfg.alpha_log2;
@@ -1133,8 +1147,11 @@ static int solve_start(psn_ctx *c, hipStream_t s, bool warm, const i64 *h_scalar
     init.need_sat = 1;
     // supplies that do not sum to zero cannot be routed: the solve ends at its first control step
     if (h_scalar[kSupplySumSlot] != 0) init.error = PSN_EINFEASIBLE_DEV;
-    *c->h_ctrl = init;
-    HIPCHK(c, hipMemcpyAsync(g.ctrl, c->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice, s));
+    return init;
+}
+static int solve_start(psn_ctx *c, hipStream_t s, bool warm, const i64 *h_scalar) {
+    *c->h_ctrl = solve_init(c, warm, h_scalar);
+    HIPCHK(c, hipMemcpyAsync(c->g.ctrl, c->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice, s));
     return PSN_OK;
 }
 // Objective and work counters of the finished solve (h_cost: 1 word, h_tally: kTallyN words, and
@@ -1307,6 +1324,12 @@ struct GroupCache {
     std::vector<std::pair<unsigned long long, unsigned long long>> key;  // (serial, upload generation) per member
     DevGraph *d_graphs = nullptr;
     int *d_status = nullptr, *h_status = nullptr;
+    // set-up and read-out of all members in one launch / one copy each: per-member records, and
+    // blocks of the members' scalar words, work counters and control blocks (device + pinned)
+    GroupAux *d_aux = nullptr, *h_aux = nullptr;
+    i64 *d_scalars = nullptr, *h_scalars = nullptr;
+    unsigned long long *d_tally = nullptr, *h_tally = nullptr;
+    Ctrl *d_ctrls = nullptr, *h_ctrls = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     int launches = 0;
@@ -1321,6 +1344,14 @@ void drop_group_cache(psn_ctx *c) {
     if (gc->d_graphs) (void)hipFree(gc->d_graphs);
     if (gc->d_status) (void)hipFree(gc->d_status);
     if (gc->h_status) (void)hipHostFree(gc->h_status);
+    if (gc->d_aux) (void)hipFree(gc->d_aux);
+    if (gc->d_scalars) (void)hipFree(gc->d_scalars);
+    if (gc->d_tally) (void)hipFree(gc->d_tally);
+    if (gc->d_ctrls) (void)hipFree(gc->d_ctrls);
+    if (gc->h_aux) (void)hipHostFree(gc->h_aux);
+    if (gc->h_scalars) (void)hipHostFree(gc->h_scalars);
+    if (gc->h_tally) (void)hipHostFree(gc->h_tally);
+    if (gc->h_ctrls) (void)hipHostFree(gc->h_ctrls);
     delete gc;
     c->gcache = nullptr;
 }
@@ -1355,6 +1386,14 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
         GCHK(counted_malloc((void **)&gc->d_graphs, G * sizeof(DevGraph)));
         GCHK(counted_malloc((void **)&gc->d_status, 2 * G * sizeof(int)));
         GCHK(counted_host_malloc((void **)&gc->h_status, 2 * 2 * G * sizeof(int)));  // two read-back slots
+        GCHK(counted_malloc((void **)&gc->d_aux, G * sizeof(GroupAux)));
+        GCHK(counted_host_malloc((void **)&gc->h_aux, G * sizeof(GroupAux)));
+        GCHK(counted_malloc((void **)&gc->d_scalars, G * kScalarSlots * sizeof(i64)));
+        GCHK(counted_host_malloc((void **)&gc->h_scalars, G * kScalarSlots * sizeof(i64)));
+        GCHK(counted_malloc((void **)&gc->d_tally, G * kTallyN * sizeof(unsigned long long)));
+        GCHK(counted_host_malloc((void **)&gc->h_tally, G * kTallyN * sizeof(unsigned long long)));
+        GCHK(counted_malloc((void **)&gc->d_ctrls, G * sizeof(Ctrl)));
+        GCHK(counted_host_malloc((void **)&gc->h_ctrls, G * sizeof(Ctrl)));
         std::vector<DevGraph> h_graphs(G);
         for (size_t i = 0; i < G; ++i) h_graphs[i] = m[i]->g;
         GCHK(hipMemcpyAsync(gc->d_graphs, h_graphs.data(), G * sizeof(DevGraph), hipMemcpyHostToDevice, s));
@@ -1367,11 +1406,30 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
         warm[i] = (flags & PSN_WARM_START) && m[i]->solved;
     }
     GCHK(hipEventRecord(lead->ev0, s));
+    // set-up of all members: one launch per step for the whole group, one copy of the statistics back
+    bool any_warm = false;
+    long long max_m2 = 1;
+    for (size_t i = 0; i < G; ++i) {
+        gc->h_aux[i] = GroupAux{m[i]->d_supply, gc->d_scalars + i * kScalarSlots, gc->d_tally + i * kTallyN, gc->d_ctrls + i, warm[i] ? 1 : 0};
+        any_warm = any_warm || warm[i];
+        max_m2 = std::max<long long>(max_m2, m[i]->m2);
+    }
+    GCHK(hipMemcpyAsync(gc->d_aux, gc->h_aux, G * sizeof(GroupAux), hipMemcpyHostToDevice, s));
+    GCHK(hipMemsetAsync(gc->d_scalars, 0, G * kScalarSlots * sizeof(i64), s));
+    const dim3 ga((unsigned)std::max<long long>(8, std::min<long long>(256, (max_m2 + kBlock * 16 - 1) / (kBlock * 16))), (unsigned)G);
+    hipLaunchKernelGGL(k_reset_group, ga, dim3(kBlock), 0, s, gc->d_graphs, gc->d_aux);
+    hipLaunchKernelGGL(k_mirror_group, ga, dim3(kBlock), 0, s, gc->d_graphs, gc->d_aux);
+    if (any_warm) hipLaunchKernelGGL(k_excess_from_flow_group, ga, dim3(kBlock), 0, s, gc->d_graphs, gc->d_aux);
+    hipLaunchKernelGGL(k_start_stats_group, ga, dim3(kBlock), 0, s, gc->d_graphs, gc->d_aux);
+    hipLaunchKernelGGL(k_sum_supply_group, dim3(16, (unsigned)G), dim3(kBlock), 0, s, gc->d_graphs, gc->d_aux);
+    GCHK(hipMemcpyAsync(gc->h_scalars, gc->d_scalars, G * kScalarSlots * sizeof(i64), hipMemcpyDeviceToHost, s));
     for (size_t i = 0; i < G; ++i)
-        if ((rc = solve_prepare(m[i], s, warm[i], &h_scalar[i * kScalarSlots])) != PSN_OK) return rc;
+        if (m[i]->g.dbg_cnt) GCHK(hipMemsetAsync(m[i]->g.dbg_cnt, 0, sizeof(unsigned), s));
     GCHK(hipStreamSynchronize(s));
-    for (size_t i = 0; i < G; ++i)
-        if ((rc = solve_start(m[i], s, warm[i], &h_scalar[i * kScalarSlots])) != PSN_OK) return rc;
+    std::memcpy(h_scalar.data(), gc->h_scalars, G * kScalarSlots * sizeof(i64));
+    for (size_t i = 0; i < G; ++i) gc->h_ctrls[i] = solve_init(m[i], warm[i], &h_scalar[i * kScalarSlots]);
+    GCHK(hipMemcpyAsync(gc->d_ctrls, gc->h_ctrls, G * sizeof(Ctrl), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_ctrl_scatter_group, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, s, gc->d_graphs, gc->d_ctrls, (int)G);
     t_b = now();
     if (fresh) {
         GCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -1409,12 +1467,22 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
     }
     replays = issued;
     t_d = now();
-    for (size_t i = 0; i < G; ++i) {
+    for (size_t i = 0; i < G; ++i)
         if (h_status[2 * i + 1]) status[i] = h_status[2 * i + 1] == PSN_EINFEASIBLE_DEV ? PSN_EINFEASIBLE : PSN_EDEVICE;
-        if ((rc = solve_finish(m[i], s, &h_cost[i], &h_tally[i * kTallyN])) != PSN_OK) return rc;
-    }
+    // read-out of all members: objective (scalar word 0 of each), work counters, control blocks
+    GCHK(hipMemsetAsync(gc->d_scalars, 0, G * kScalarSlots * sizeof(i64), s));
+    hipLaunchKernelGGL(k_total_cost_group, ga, dim3(kBlock), 0, s, gc->d_graphs, gc->d_aux);
+    hipLaunchKernelGGL(k_tally_sum_group, dim3(1, (unsigned)G), dim3(64 * kTallyN), 0, s, gc->d_graphs, gc->d_aux, kSweepWaves);
+    GCHK(hipMemcpyAsync(gc->h_scalars, gc->d_scalars, G * kScalarSlots * sizeof(i64), hipMemcpyDeviceToHost, s));
+    GCHK(hipMemcpyAsync(gc->h_tally, gc->d_tally, G * kTallyN * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    GCHK(hipMemcpyAsync(gc->h_ctrls, gc->d_ctrls, G * sizeof(Ctrl), hipMemcpyDeviceToHost, s));
     GCHK(hipEventRecord(lead->ev1, s));
     GCHK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < G; ++i) {
+        h_cost[i] = gc->h_scalars[i * kScalarSlots];
+        std::memcpy(&h_tally[i * kTallyN], gc->h_tally + i * kTallyN, kTallyN * sizeof(unsigned long long));
+        *m[i]->h_ctrl = gc->h_ctrls[i];
+    }
     GCHK(hipEventElapsedTime(&ms, lead->ev0, lead->ev1));
 #undef GCHK
     t_e = now();

@@ -99,6 +99,17 @@ struct DevGraph {
 };
 constexpr unsigned kDbgCap = 1u << 16;
 
+// Per member of a lockstep group: what the group's set-up and read-out launches need besides the
+// member's DevGraph (the scalar / counter / control words live in blocks of the group, so that
+// one copy serves all members).
+struct GroupAux {
+    const i64 *supply;
+    i64 *scalar;                    // kScalarSlots words of this member
+    unsigned long long *tally_out;  // kTallyN words
+    Ctrl *ctrl_out;
+    int warm;
+};
+
 __global__ void k_push(DevGraph g, int k);
 __global__ void k_relabel_compact(DevGraph g, int k, int do_relabel);
 __global__ void k_saturate(DevGraph g);
@@ -120,6 +131,12 @@ __global__ void k_excess_from_flow(DevGraph g);
 __global__ void k_total_cost(DevGraph g, i64 *out);
 __global__ void k_flow(DevGraph g, int *flow);
 __global__ void k_tally_sum(DevGraph g, unsigned long long *out, int nslots);
+__global__ void k_reset_group(const DevGraph *gs, const GroupAux *aux);
+__global__ void k_mirror_group(const DevGraph *gs, const GroupAux *aux);
+__global__ void k_excess_from_flow_group(const DevGraph *gs, const GroupAux *aux);
+__global__ void k_total_cost_group(const DevGraph *gs, const GroupAux *aux);
+__global__ void k_tally_sum_group(const DevGraph *gs, const GroupAux *aux, int nslots);
+__global__ void k_ctrl_scatter_group(const DevGraph *gs, const Ctrl *init, int count);
 __global__ void k_eval_costs(DevGraph g, int E, int N, int K, const i64 *cap_cpu, const i64 *cap_mem, const i64 *used_cpu,
                              const i64 *used_mem, const i64 *req_cpu, const i64 *req_mem, const i64 *ec_arc_base, int *mcost,
                              int *mocap);

@@ -1280,7 +1280,7 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
 }
 
 // ------------------------------------------------------------ setup / readout kernels
-__global__ __launch_bounds__(kBlock) void k_reset(DevGraph g, const i64 *supply, int keep_flow) {
+__device__ __forceinline__ void reset_body(const DevGraph &g, const i64 *supply, int keep_flow, int zero_tally) {
     for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) {
         if (!keep_flow) g.cap[a] = g.ocap[a];
     }
@@ -1291,22 +1291,23 @@ __global__ __launch_bounds__(kBlock) void k_reset(DevGraph g, const i64 *supply,
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n_hub_segs; i += gridDim.x * kBlock) {
         g.seg_scan[i] = kInf; g.seg_add[0][i] = kNegInf; g.seg_add[1][i] = kNegInf;
     }
+    if (zero_tally)
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < kSweepWaves * kTallyN; i += gridDim.x * kBlock) g.tally[i] = 0;
 }
 // rcap mirrors cap[rev]; excess from scratch for a kept flow: supply - outflow + inflow,
 // with outflow(a) = ocap[a] - cap[a] counted on arcs where it is positive.
-__global__ __launch_bounds__(kBlock) void k_mirror(DevGraph g, const i64 *supply, int recompute_excess) {
+__device__ __forceinline__ void mirror_body(const DevGraph &g, const i64 *supply, int recompute_excess) {
     if (recompute_excess)
         for (int v = blockIdx.x * kBlock + threadIdx.x; v < g.n; v += gridDim.x * kBlock) g.excess[v] = supply[v];
-    (void)supply;
     for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) g.rcap[a] = g.cap[g.rev[a]];
 }
-__global__ __launch_bounds__(kBlock) void k_excess_from_flow(DevGraph g) {
+__device__ __forceinline__ void excess_from_flow_body(const DevGraph &g) {
     for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) {
         const i64 f = (i64)g.ocap[a] - g.cap[a];
         if (f > 0) { aadd64(&g.excess[g.tail[a]], -f); aadd64(&g.excess[g.head[a]], f); }
     }
 }
-__global__ __launch_bounds__(kBlock) void k_total_cost(DevGraph g, i64 *out) {
+__device__ __forceinline__ void total_cost_body(const DevGraph &g, i64 *out) {
     i64 s = 0;
     for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) {
         const i64 f = (i64)g.ocap[a] - g.cap[a];
@@ -1315,10 +1316,28 @@ __global__ __launch_bounds__(kBlock) void k_total_cost(DevGraph g, i64 *out) {
     s = (i64)wave_sum_u64((unsigned long long)s);
     if (lane_id() == 0 && s) aadd64(out, s);
 }
+__global__ __launch_bounds__(kBlock) void k_reset(DevGraph g, const i64 *supply, int keep_flow) { reset_body(g, supply, keep_flow, 0); }
+__global__ __launch_bounds__(kBlock) void k_mirror(DevGraph g, const i64 *supply, int recompute_excess) { mirror_body(g, supply, recompute_excess); }
+__global__ __launch_bounds__(kBlock) void k_excess_from_flow(DevGraph g) { excess_from_flow_body(g); }
+__global__ __launch_bounds__(kBlock) void k_total_cost(DevGraph g, i64 *out) { total_cost_body(g, out); }
+// The same for the members of a lockstep group, one launch for all of them (blockIdx.y picks the
+// member; what differs per member comes from its GroupAux record).
+__global__ __launch_bounds__(kBlock) void k_reset_group(const DevGraph *__restrict__ gs, const GroupAux *__restrict__ aux) {
+    reset_body(gs[blockIdx.y], aux[blockIdx.y].supply, aux[blockIdx.y].warm, 1);
+}
+__global__ __launch_bounds__(kBlock) void k_mirror_group(const DevGraph *__restrict__ gs, const GroupAux *__restrict__ aux) {
+    mirror_body(gs[blockIdx.y], aux[blockIdx.y].supply, aux[blockIdx.y].warm);
+}
+__global__ __launch_bounds__(kBlock) void k_excess_from_flow_group(const DevGraph *__restrict__ gs, const GroupAux *__restrict__ aux) {
+    if (aux[blockIdx.y].warm) excess_from_flow_body(gs[blockIdx.y]);
+}
+__global__ __launch_bounds__(kBlock) void k_total_cost_group(const DevGraph *__restrict__ gs, const GroupAux *__restrict__ aux) {
+    total_cost_body(gs[blockIdx.y], aux[blockIdx.y].scalar);
+}
 __global__ __launch_bounds__(kBlock) void k_flow(DevGraph g, int *flow) {
     for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < g.m2; a += gridDim.x * kBlock) flow[a] = g.ocap[a] - g.cap[a];
 }
-__global__ void k_tally_sum(DevGraph g, unsigned long long *out, int nslots) {
+__device__ __forceinline__ void tally_sum_body(const DevGraph &g, unsigned long long *out, int nslots) {
     // one wave per counter
     const int w = threadIdx.x >> 6;
     if (w >= kTallyN) return;
@@ -1326,6 +1345,18 @@ __global__ void k_tally_sum(DevGraph g, unsigned long long *out, int nslots) {
     for (int i = lane_id(); i < nslots; i += 64) s += g.tally[(size_t)i * kTallyN + w];
     s = wave_sum_u64(s);
     if (lane_id() == 0) out[w] = s;
+}
+__global__ void k_tally_sum(DevGraph g, unsigned long long *out, int nslots) { tally_sum_body(g, out, nslots); }
+// work counters and control block of every member of a group, into the group's contiguous read-back blocks
+__global__ void k_tally_sum_group(const DevGraph *__restrict__ gs, const GroupAux *__restrict__ aux, int nslots) {
+    const DevGraph &g = gs[blockIdx.y];
+    if (threadIdx.x == 0) *aux[blockIdx.y].ctrl_out = *g.ctrl;
+    tally_sum_body(g, aux[blockIdx.y].tally_out, nslots);
+}
+// the control blocks the members of a group start from, out of the group's upload block
+__global__ void k_ctrl_scatter_group(const DevGraph *__restrict__ gs, const Ctrl *__restrict__ init, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) *gs[i].ctrl = init[i];
 }
 
 // ------------------------------------------------------------- arc-cost model (K1)
