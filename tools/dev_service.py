@@ -22,7 +22,7 @@ def main():
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     check = "nocheck" not in sys.argv
     cl = synth.make_cluster(cfg, seed)
-    with pa.SchedulerService(device=0) as s:
+    with pa.SchedulerService(device=0, reschedule_running="resched" in sys.argv) as s:
         t = time.time(); uids = feed_cluster(s, cl); print(f"feed {time.time() - t:.2f} s")
         t = time.time(); d = s.Schedule(); show("cold ", s.stats(), len(d), (time.time() - t) * 1e3)
         if check:
