@@ -378,22 +378,31 @@ __device__ __forceinline__ void max_violation_body(const DevGraph &g, i64 *out) 
 
 // Sum of the supplies of the resident network (psn_update_supplies may have unbalanced them) and
 // the number of vertices that hold supply.
-__device__ __forceinline__ void sum_supply_body(const i64 *supply, int n, i64 *out, i64 *n_sources) {
-    i64 sm = 0;
+__device__ __forceinline__ void sum_supply_body(const i64 *supply, int n, i64 *out, i64 *n_sources, i64 *units) {
+    i64 sm = 0, un = 0;
     unsigned src = 0;
-    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) { sm += supply[v]; src += supply[v] > 0; }
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
+        sm += supply[v];
+        src += supply[v] > 0;
+        un += supply[v] > 0 ? supply[v] : 0;
+    }
     sm = (i64)wave_sum_u64((unsigned long long)sm);
+    un = (i64)wave_sum_u64((unsigned long long)un);
     src = wave_sum_u32(src);
     if ((threadIdx.x & 63) == 0 && sm) __hip_atomic_fetch_add(out, sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((threadIdx.x & 63) == 0 && src) __hip_atomic_fetch_add(n_sources, (i64)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0 && src) {
+        __hip_atomic_fetch_add(n_sources, (i64)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(units, un, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-constexpr int kScalarSlots = 40;
+constexpr int kScalarSlots = 48;
 constexpr int kSupplySumSlot = 38;  // d_scalar: [0] total cost, [1] max violation, [2..35] cost statistics, [36] vertices with supply, [38] supply sum
 constexpr int kSourcesSlot = 36;
+constexpr int kSupplyUnitsSlot = 40;  // sum of the positive supplies
 __global__ void k_cost_stats(DevGraph g, i64 *out) { cost_stats_body(g, out); }
 __global__ void k_max_violation(DevGraph g, i64 *out) { max_violation_body(g, out); }
-__global__ void k_sum_supply(const i64 *supply, int n, i64 *out, i64 *n_sources) { sum_supply_body(supply, n, out, n_sources); }
+__global__ void k_sum_supply(const i64 *supply, int n, i64 *out, i64 *n_sources, i64 *units) { sum_supply_body(supply, n, out, n_sources, units); }
 // for the members of a lockstep group (blockIdx.y picks the member): the statistics the first
 // epsilon comes from - of the costs for a cold member, of the kept prices' violations for a warm one
 __global__ void k_start_stats_group(const DevGraph *__restrict__ gs, const GroupAux *__restrict__ aux) {
@@ -403,7 +412,7 @@ __global__ void k_start_stats_group(const DevGraph *__restrict__ gs, const Group
 }
 __global__ void k_sum_supply_group(const DevGraph *__restrict__ gs, const GroupAux *__restrict__ aux) {
     const GroupAux &x = aux[blockIdx.y];
-    sum_supply_body(x.supply, gs[blockIdx.y].n, x.scalar + kSupplySumSlot, x.scalar + kSourcesSlot);
+    sum_supply_body(x.supply, gs[blockIdx.y].n, x.scalar + kSupplySumSlot, x.scalar + kSourcesSlot, x.scalar + kSupplyUnitsSlot);
 }
 
 // Marks and counts the vertex cover of the resident network on the context's stream; the count is
@@ -1100,7 +1109,7 @@ static int solve_prepare(psn_ctx *c, hipStream_t s, bool warm, i64 *h_scalar) {
     if (g.dbg_cnt) HIPCHK(c, hipMemsetAsync(g.dbg_cnt, 0, sizeof(unsigned), s));
     if (!warm) hipLaunchKernelGGL(k_cost_stats, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 2);
     if (warm) hipLaunchKernelGGL(k_max_violation, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 1);
-    hipLaunchKernelGGL(k_sum_supply, dim3(std::max(1, std::min(64, (g.n + kBlock - 1) / kBlock))), dim3(kBlock), 0, s, c->d_supply, g.n, c->d_scalar + kSupplySumSlot, c->d_scalar + kSourcesSlot);
+    hipLaunchKernelGGL(k_sum_supply, dim3(std::max(1, std::min(64, (g.n + kBlock - 1) / kBlock))), dim3(kBlock), 0, s, c->d_supply, g.n, c->d_scalar + kSupplySumSlot, c->d_scalar + kSourcesSlot, c->d_scalar + kSupplyUnitsSlot);
     HIPCHK(c, hipMemcpyAsync(h_scalar, c->d_scalar, kScalarSlots * sizeof(i64), hipMemcpyDeviceToHost, s));
     return PSN_OK;
 }
@@ -1109,16 +1118,17 @@ static Ctrl solve_init(psn_ctx *c, bool warm, const i64 *h_scalar) {
     const DevGraph &g = c->g;
     Ctrl init{};
     init.alpha_log2 = c->cfg.alpha_log2;
-    // phases other than the last stop at about 1 % of the sources still active (see k_begin)
-    int tail_div = kTailDiv;
-    if (const char *ev = std::getenv("PSN_TAIL_DIV")) tail_div = std::max(1, atoi(ev));
-    init.tail_items = (int)std::min<i64>(1 << 20, h_scalar[kSourcesSlot] / tail_div);
-    if (const char *ev = std::getenv("PSN_TAIL_ITEMS")) init.tail_items = std::max(0, atoi(ev));
-    // ... or when no more than a couple of dozen vertices are active, whatever their size (a task class
-    // alone is some 90 work items: a network with few sources never gets down to few items)
-    init.tail_vertices = (int)std::min<i64>(kTailVertices, h_scalar[kSourcesSlot] / 32);
-    if (const char *ev = std::getenv("PSN_TAIL_VERTICES")) init.tail_vertices = std::max(0, atoi(ev));
-    if (std::getenv("PSN_TAIL_DIV") || std::getenv("PSN_TAIL_ITEMS")) init.tail_vertices = std::min(init.tail_vertices, init.tail_items);
+    {
+        // Phases other than the last stop when little excess is left on its way (see k_begin): about
+        // 6 % of the supply of a small network, never more than kTailMax units - the last phase has to
+        // route what they leave, one unit after the other, and past some 200 units that costs more
+        // than the tails it saves, whatever the size of the network.
+        const i64 supply_units = h_scalar[kSupplyUnitsSlot];
+        i64 u = std::max<i64>(kTailMin, std::min<i64>(kTailMax, supply_units / kTailDiv));
+        if (const char *ev = std::getenv("PSN_TAIL_DIV")) u = supply_units / std::max(1, atoi(ev));  // tests: far more
+        if (const char *ev = std::getenv("PSN_TAIL_UNITS")) u = std::max(0, atoi(ev));
+        init.tail_units = (int)std::min<i64>(65534, u);
+    }
     int shift0;
     if (!warm) {
         // Zero flow with zero prices is 0-optimal when no usable arc has a negative cost, so the
@@ -1243,6 +1253,10 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
             c->kt_used = 0;
         }
         if (dbg_phases) {
+            {
+                const unsigned *lc = h.list_cnt[c->rounds & 1];
+                if (h.rounds_on && std::getenv("PSN_DEBUG_PHASES")) fprintf(stderr, "     shift %d: items %u units %u\n", h.eps_shift, lc[0] + lc[1], lc[2]);
+            }
             if (h.eps_shift != last_shift && last_shift >= 0) { phase_log += " " + std::to_string(last_shift) + ":" + std::to_string(phase_replays + 1); phase_replays = 0; }
             else ++phase_replays;
             last_shift = h.eps_shift;

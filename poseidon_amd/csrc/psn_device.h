@@ -27,8 +27,7 @@ constexpr int kClsLean = 4;      // cls[] bit: every step of the row is made of 
 constexpr int kClsSeg = 1;       // counter slot of the (vertex, segment) item lists (slot 0: lane list)
 constexpr int kHubPull = -2;     // hub_of[] value of a pull vertex (see DevGraph::pull_list); -1: an ordinary vertex
 constexpr int kMaxHubs = 128;    // highest-degree vertices whose atomics are pre-combined in LDS per workgroup
-constexpr int kTailVertices = 24;  // Ctrl::tail_vertices = min(this, vertices with supply / 32)
-constexpr int kTailDiv = 128;     // Ctrl::tail_items = vertices with supply / kTailDiv
+constexpr int kTailDiv = 16, kTailMin = 16, kTailMax = 176;  // Ctrl::tail_units = total supply / kTailDiv, within [kTailMin, kTailMax]
 constexpr int kGuIters = 12;     // frontier expansions per replay (multiple of 3)
 constexpr int PSN_EINFEASIBLE_DEV = -4;
 
@@ -42,12 +41,12 @@ enum { kTallyScans = 0, kTallyPushes, kTallyRelabels, kTallyVisits, kTallyGuScan
 struct Ctrl {
     i64 eps;
     int eps_shift, alpha_log2;
-    int tail_items, tail_vertices;  // a phase that is not the last one ends when its work list has shrunk to tail_items items or to tail_vertices vertices
+    int tail_units;  // a phase that is not the last one ends when the active vertices hold no more than this many units of excess
     int need_sat, need_gu, gu_active;
     int sat_on, gu_on, gu_init_on, rounds_on;
     int done, error;
     unsigned epoch, gu_stamp_base;
-    unsigned list_cnt[2][4];
+    unsigned list_cnt[2][4];  // per list parity: lane items, wave items, units of excess at the listed vertices, -
     unsigned fr_cnt[3][4];
     int gu_phase[2];  // global update, read by expansion k at [k & 1], written at [(k + 1) & 1]: 0 expanding, 1 the pull sweep just ran, 2 converged
     unsigned long long tally_refines, tally_gus;

@@ -555,13 +555,14 @@ __device__ __forceinline__ HubTurn hub_fetch(const DevGraph &g, int hv) {
     h.r0 = g.row[hv]; h.r1 = g.row[hv + 1]; h.seg1 = g.seg1_of[hv];
     return h;
 }
-constexpr int kCntVertices = 3;  // work-list counter slot: active vertices (a split vertex counts once, whatever its items)
+constexpr int kCntUnits = 2;     // work-list counter slot: units of excess at the listed vertices (a vertex counts for at most 2^16 - 1)
+__device__ __forceinline__ unsigned excess_units(i64 e) { return e > 0 ? (unsigned)(e < 65535 ? e : 65535) : 0u; }
 __device__ __forceinline__ void hub_decide(const DevGraph &g, HubTurn &h, bool do_relabel, i64 eps, unsigned rot, Tally &t, unsigned *cnt) {
     h.act = h.e > 0;
     h.nseg = (h.r1 - h.r0 + kWSeg - 1) / kWSeg;
     h.first = (rot ^ (unsigned)h.v * 0x9E3779B9u) % h.nseg;
     if (threadIdx.x == 0) {
-        if (h.act) __hip_atomic_fetch_add(&cnt[kCntVertices], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h.act) __hip_atomic_fetch_add(&cnt[kCntUnits], excess_units(h.e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (h.act && do_relabel && h.c != kInf && h.c != kNegInf && h.c <= h.p) { g.price[h.v] = h.c - eps; t.c[kTallyRelabels]++; }
         const i64 nc = h.act ? kNegInf : kInf;
         if (h.c != nc) g.cand[h.v] = nc;
@@ -632,11 +633,11 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
             if (seg1[i] == 0 && c[i] != nc) g.cand[v[i]] = nc;
         }
         {
-            unsigned nact = 0;
+            unsigned units = 0;
 #pragma unroll
-            for (int i = 0; i < kVpt; ++i) nact += act[i];
-            nact = wave_sum_u32(nact);
-            if (lane_id() == 0 && nact) __hip_atomic_fetch_add(&ct->list_cnt[dst][kCntVertices], nact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < kVpt; ++i) units += act[i] ? excess_units(e[i]) : 0u;
+            units = wave_sum_u32(units);
+            if (lane_id() == 0 && units) __hip_atomic_fetch_add(&ct->list_cnt[dst][kCntUnits], units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app, hub_segs, &hub_base);
         if (hub_state == 1) { if (hub.act) append_hub(hub, hub_base, g.list_seg[dst]); hub_state = 2; }
@@ -1241,10 +1242,10 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
         // the next phase's saturation sets free (every phase starts by restoring its own
         // epsilon-optimality, whatever pseudoflow it is given).  The long tail of a phase - a
         // handful of units moving one arc per round - is thereby run once, at the end of the last
-        // phase, instead of once per phase.  "Little left" is few work items, or few active vertices
-        // (a task class alone is some 90 items: a network with few sources and large vertices never
-        // gets down to few items).
-        if (left == 0 || (ct->eps_shift > 0 && (left <= (unsigned)ct->tail_items || c[kCntVertices] <= (unsigned)ct->tail_vertices))) {
+        // phase, instead of once per phase.  What is left is measured in units of excess at the
+        // active vertices, not in work items: a few large vertices that still hold thousands of
+        // units (an over-subscribed cluster) are not a tail.
+        if (left == 0 || (ct->eps_shift > 0 && c[kCntUnits] <= (unsigned)ct->tail_units)) {
             if (ct->eps_shift == 0) {
                 ct->done = 1;
             } else {

@@ -431,9 +431,10 @@ def test_network_built_on_the_device_equals_the_host_builder(cfg, seed):
 
 @pytest.mark.parametrize("div", ["1", "3", "16"])
 def test_phases_cut_short_still_end_at_the_optimum(solver, monkeypatch, div):
-    """Phases other than the last may stop with a few items of excess still active (by default
-    1/128 of the vertices with supply; here far more, so that small networks exercise it): the
-    leftovers are routed by the later phases and the result is the same optimum, certified."""
+    """Phases other than the last may stop with some units of excess still on their way (by default
+    1/16 of the supply, 176 units at most; here all, a third and a sixteenth of it without the upper
+    bound, so that small networks exercise it): the leftovers are routed by the later phases and the
+    result is the same optimum, certified."""
     monkeypatch.setenv("PSN_TAIL_DIV", div)
     rng = np.random.default_rng(int(div))
     for trial in range(12):

@@ -54,6 +54,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             print(f"  {name}: mean {np.mean(ms):.2f} min {min(ms):.2f} max {max(ms):.2f} ms rounds {r.rounds} gus {r.global_updates} cost {'ok' if rc == 0 and tc == r.total_cost else 'MISMATCH'}", flush=True)
 else:
     reps = sys.argv[1] if len(sys.argv) > 1 else "5"
-    for label, env in (("phases end early (default)", {}), ("phases run to the end", {"PSN_TAIL_DIV": "1000000000", "PSN_TAIL_VERTICES": "0"})):
+    for label, env in (("phases end early (default)", {}), ("phases run to the end", {"PSN_TAIL_UNITS": "0"})):
         print(label, flush=True)
         subprocess.run([sys.executable, __file__, "child", reps], env={**os.environ, **env}, check=True)
