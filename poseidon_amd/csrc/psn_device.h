@@ -27,7 +27,7 @@ constexpr int kClsLean = 4;      // cls[] bit: every step of the row is made of 
 constexpr int kClsSeg = 1;       // counter slot of the (vertex, segment) item lists (slot 0: lane list)
 constexpr int kHubPull = -2;     // hub_of[] value of a pull vertex (see DevGraph::pull_list); -1: an ordinary vertex
 constexpr int kMaxHubs = 128;    // highest-degree vertices whose atomics are pre-combined in LDS per workgroup
-constexpr int kTailDiv = 16, kTailMin = 16, kTailMax = 176;  // Ctrl::tail_units = total supply / kTailDiv, within [kTailMin, kTailMax]
+constexpr double kTailFactor = 0.6;  // Ctrl::tail_units = kTailFactor * sqrt(total supply)
 constexpr int kGuIters = 12;     // frontier expansions per replay (multiple of 3)
 constexpr int PSN_EINFEASIBLE_DEV = -4;
 
