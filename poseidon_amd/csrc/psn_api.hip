@@ -298,12 +298,26 @@ __global__ void k_lean_init(const unsigned *row, int n, unsigned *lean_stop) {
     for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) lean_stop[v] = row[v] + ((row[v + 1] - row[v]) & ~7u);
 }
 __global__ void k_lean_scan(const unsigned *row, unsigned m2, const int *head, const int *tail, unsigned *lean_stop) {
-    for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < m2; a += gridDim.x * kBlock) {
-        const int v = tail[a];
-        if (((a - row[v]) & 7u) || a + 8 > row[v + 1]) continue;  // not the first arc of a complete group
-        bool same = true;
-        for (int j = 1; j < 8; ++j) same &= head[a + j] == head[a];
-        if (!same) atomicMin(&lean_stop[v], a);
+    // a wave's 64 consecutive arcs mostly belong to one vertex: its lanes agree on the first group that
+    // is not uniform and one of them reports it (thousands of same-address atomics per large row otherwise)
+    const unsigned m2_round = (m2 + 63u) & ~63u;
+    for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < m2_round; a += gridDim.x * kBlock) {
+        const bool in = a < m2;
+        const int v = tail[in ? a : m2 - 1];
+        unsigned bad = 0xFFFFFFFFu;
+        if (in && !((a - row[v]) & 7u) && a + 8 <= row[v + 1] && lean_stop[v] > a) {  // first arc of a complete group inside the prefix so far
+            bool same = true;
+            for (int j = 1; j < 8; ++j) same &= head[a + j] == head[a];
+            if (!same) bad = a;
+        }
+        const int v0 = __builtin_amdgcn_readfirstlane(v);
+        if (__all(v == v0)) {
+            unsigned m = bad;
+            for (int d = 32; d; d >>= 1) { const unsigned y = __shfl_xor(m, d); m = y < m ? y : m; }
+            if ((threadIdx.x & 63) == 0 && m != 0xFFFFFFFFu) atomicMin(&lean_stop[v0], m);
+        } else if (bad != 0xFFFFFFFFu) {
+            atomicMin(&lean_stop[v], bad);
+        }
     }
 }
 __global__ void k_lean_flag(const unsigned *row, int n, const unsigned *lean_stop, unsigned char *cls) {
