@@ -47,6 +47,12 @@ __device__ __forceinline__ T ld_sel(bool need, const T *p, const void *spare) {
 }
 
 // ------------------------------------------------------------------ wave primitives
+// Control words a kernel reads at its start are asked for together and waited for once: read one
+// after the other behind the branches that look at them, each costs a round trip to memory of its
+// own (the launch before wrote them), which is most of the duration of a launch with little work.
+#define CTRL_TOGETHER4(a, b, c, d) asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d))
+#define CTRL_TOGETHER5(a, b, c, d, e) asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d), "s"(e))
+#define CTRL_TOGETHER8(a, b, c, d, e, f, g_, h) asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d), "s"(e), "s"(f), "s"(g_), "s"(h))
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
@@ -507,9 +513,11 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
 
 __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     Ctrl *ct = g.ctrl;
-    if (!ct->rounds_on) return;
     const unsigned *cnt = ct->list_cnt[k & 1];
-    const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg];
+    const int on = ct->rounds_on;
+    const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg], epoch = ct->epoch;
+    CTRL_TOGETHER4(on, nlow, nseg, epoch);
+    if (!on) return;
     if (blockIdx.x == 0 && threadIdx.x < 4) ct->list_cnt[(k + 1) & 1][threadIdx.x] = 0;
     if (nlow + nseg == 0) return;
     if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -520,7 +528,7 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     const HubAcc hb{s_add, s_max};
     hub_init(hb, kNegInf);
     const i64 S = g.scale;
-    const unsigned salt = ct->epoch * 64u + (unsigned)k;
+    const unsigned salt = epoch * 64u + (unsigned)k;
     const int2 *lowl = g.list_low[k & 1];
     const int4 *segl = g.list_seg[k & 1];
     const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -602,14 +610,15 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
     fetch((int)blockIdx.x * span);
     // the hub of this workgroup: fetched with the control words as well
     const int hub0 = (int)blockIdx.x < g.nhubs ? g.hub_vertex[blockIdx.x] : -1;
-    if (!ct->rounds_on) return;
-    const int dst = do_relabel ? (k + 1) & 1 : 0;
-    if (do_relabel) {
-        const unsigned *cnt = ct->list_cnt[k & 1];
-        if (cnt[kClsLow] + cnt[kClsSeg] == 0) return;  // nothing was active
-    }
+    const unsigned *cnt = ct->list_cnt[k & 1];
+    const int on = ct->rounds_on;
+    const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg], epoch = ct->epoch;
     const i64 eps = ct->eps;
-    const unsigned rot = mix32(ct->epoch, (unsigned)k);
+    CTRL_TOGETHER5(on, nlow, nseg, epoch, eps);
+    if (!on) return;
+    const int dst = do_relabel ? (k + 1) & 1 : 0;
+    if (do_relabel && nlow + nseg == 0) return;  // nothing was active
+    const unsigned rot = mix32(epoch, (unsigned)k);
     Tally t;
     __shared__ AppendLds s_app;
     __shared__ unsigned s_hub_base;
@@ -847,16 +856,20 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
 
 __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     Ctrl *ct = g.ctrl;
-    if (!ct->gu_on) return;
     const int src = k % 3, dst = (k + 1) % 3, clr = (k + 2) % 3;
     const unsigned *cnt = ct->fr_cnt[src];
+    const int on = ct->gu_on;
     const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg];
+    const int phase = ct->gu_phase[k & 1];
+    const unsigned npull = *g.pull_cnt;
+    const int sh = ct->eps_shift;
+    const unsigned stamp_base = ct->gu_stamp_base, epoch = ct->epoch;
+    CTRL_TOGETHER8(on, nlow, nseg, phase, npull, sh, stamp_base, epoch);
+    if (!on) return;
     if (blockIdx.x == 0 && threadIdx.x < 4) ct->fr_cnt[clr][threadIdx.x] = 0;
     // What this launch does follows from words it does not write: the frontier it reads and the
     // phase the launch before it left.  A dry frontier is followed by one sweep over the pull
     // vertices; if that queues nothing either, the update has converged.
-    const int phase = ct->gu_phase[k & 1];
-    const unsigned npull = *g.pull_cnt;
     const bool dry = nlow + nseg == 0;
     const bool do_pull = phase == 0 && dry && npull != 0;
     const int phase_out = phase == 2 ? 2 : (!dry ? 0 : (do_pull ? 1 : 2));
@@ -879,9 +892,8 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     int2 *dlow = g.fr_low[dst];
     int4 *dseg = g.fr_seg[dst];
     const i64 S = g.scale;
-    const int sh = ct->eps_shift;
-    const unsigned stamp = (ct->gu_stamp_base + (unsigned)k) % 65535u + 1u;  // 16 bits, never 0
-    const unsigned rot = mix32(ct->epoch, stamp);
+    const unsigned stamp = (stamp_base + (unsigned)k) % 65535u + 1u;  // 16 bits, never 0
+    const unsigned rot = mix32(epoch, stamp);
     const int lane = lane_id();
     const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * kBlock) >> 6;
