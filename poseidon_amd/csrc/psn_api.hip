@@ -1231,6 +1231,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     long long replays = 0;
     int status = PSN_OK;
     const bool dbg_phases = std::getenv("PSN_DEBUG_SOLVE") != nullptr;
+    const auto t_host0 = std::chrono::steady_clock::now();
     std::string phase_log;
     int last_shift = -1; long long phase_replays = 0;
     // Graph replays are kept two deep in the stream: while the host looks at the control block replay i
@@ -1270,7 +1271,10 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
         if (dbg_phases) {
             {
                 const unsigned *lc = h.list_cnt[c->rounds & 1];
-                if (h.rounds_on && std::getenv("PSN_DEBUG_PHASES")) fprintf(stderr, "     shift %d: items %u units %u\n", h.eps_shift, lc[0] + lc[1], lc[2]);
+                if (h.rounds_on && std::getenv("PSN_DEBUG_PHASES")) {
+                    const double at = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+                    fprintf(stderr, "     shift %d: items %u units %u  at %.2f ms (host clock)\n", h.eps_shift, lc[0] + lc[1], lc[2], at);
+                }
             }
             if (h.eps_shift != last_shift && last_shift >= 0) { phase_log += " " + std::to_string(last_shift) + ":" + std::to_string(phase_replays + 1); phase_replays = 0; }
             else ++phase_replays;
