@@ -204,14 +204,17 @@ int psn_solve(psn_ctx *ctx, uint32_t flags, psn_result *out);
 
 /* Solve `count` independent networks, one per context (each uploaded and priced
  * beforehand, all contexts distinct).  Contexts on one device with the same solver
- * configuration are solved in lockstep groups of up to 128 (environment PSN_BATCH_GROUP:
- * 1..256; 1 = one at a time): every stage of the solve is one launch for the whole group,
+ * configuration are solved in lockstep groups of up to 128 - two groups of half the contexts
+ * each from eight contexts on, since two groups side by side fill each other's gaps
+ * (environment PSN_BATCH_GROUP: 1..256 fixes the largest group instead; 1 = one at a time):
+ * every stage of the solve is one launch for the whole group,
  * which is what bounds many small networks; the networks share nothing and each stops
  * when it is done.  Fewer than four contexts that could share a group are solved one after
  * the other instead (a group's launches carry every member's idle stages).  The contexts may
  * live on several GPUs of the node: grouping is per device, and the groups are spread over
- * `workers` host threads (0 -> 4, or two per device when that is more; never fewer than one
- * per device), each driving one stream, so the devices work side by side.  A group's replay
+ * `workers` host threads (0 -> two per device when every context is in a group, else 4 or
+ * two per device when that is more; never fewer than one per device), each driving one
+ * stream, so the devices work side by side.  A group's replay
  * graph is kept by its first context and reused while the same contexts, in the same order,
  * keep their uploads.  out[i] receives the result of ctxs[i] (solve_ms of a group member is the
  * group's time); the first error code is returned, the other solves still run.  This is
