@@ -1227,7 +1227,8 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     HIPCHK(c, hipStreamSynchronize(s));
     if ((rc = solve_start(c, s, warm, h_scalar)) != PSN_OK) return rc;
     // ---- replay until done
-    const long long max_replays = 200000;
+    long long max_replays = 200000;
+    if (const char *ev = std::getenv("PSN_MAX_REPLAYS")) max_replays = std::max(1, atoi(ev));  // development: stop a solve half way (PSN_ELIMIT)
     long long replays = 0;
     int status = PSN_OK;
     const bool dbg_phases = std::getenv("PSN_DEBUG_SOLVE") != nullptr;

@@ -369,17 +369,80 @@ __device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, in
     if (e != e0) aadd64(&g.excess[u], e - e0);
 }
 
+// One step of a solo item whose lanes found at most 64 residual arcs between them (a machine's
+// row: 512 reverse arcs, of which the few that carry flow are residual, and the arc to the sink).
+// The residual arcs are handed out one per lane through the wave's LDS record, so the step costs
+// one arc's worth of instructions per lane instead of nine; the prefix order of the grants is
+// the order of the records, which is the (rotated) lane order of the dense step.
+struct StepOut { i64 here; bool stop; };
+__device__ __forceinline__ StepOut push_step_sparse(const DevGraph &g, const HubAcc &hb, int2 *slive, const int (&cp)[9], unsigned lm,
+                                                    unsigned off, unsigned total_live, unsigned a0, unsigned at, unsigned safe, i64 pu,
+                                                    i64 S, i64 &e, int par, Tally &t) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+        if ((lm >> j) & 1u) { slive[off] = make_int2((int)arc9(a0, at, j), cp[j]); ++off; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool has = (unsigned)lane < total_live;
+    const int2 rec = slive[has ? lane : 0];
+    const unsigned a = has ? (unsigned)rec.x : safe;
+    const int c = has ? rec.y : 0;
+    const int hd = g.head[a], cs = g.cost[a], rv = g.rev[a], cr = g.rcap[a];  // one round trip for all four
+    const i64 ph = ld_sel(has, &g.price[hd], g.spare);
+    const int hub = ld_sel(has, &g.hub_of[hd], g.spare);
+    const i64 key = ph - (i64)cs * S;
+    const bool adm = has && key > pu;
+    const i64 want = adm ? (i64)c : 0;
+    int d = 0;
+    bool stop = false;
+    if (__ballot(want > 0)) {
+        const i64 incl = wave_incl_scan(want);
+        const i64 total = __shfl(incl, 63);
+        const i64 granted = total < e ? total : e;
+        e -= granted;
+        const i64 mine = granted - (incl - want);  // what this lane may push
+        if (adm && mine > 0) {
+            d = (int)(mine < (i64)c ? mine : (i64)c);
+            const int na = c - d, nr = cr + d;
+            g.cap[a] = na; g.cap[rv] = nr; g.rcap[a] = nr; g.rcap[rv] = na;
+            const i64 kr = pu + (i64)cs * S;  // key of the new residual arc (v,u)
+            if (hub >= 0) { lds_add(&hb.add[hub], (i64)d); lds_max(&hb.ext[hub], kr); seg_note(g, hub, rv, kr, par); }
+            else { aadd64(&g.excess[hd], (i64)d); amax64(&g.cand[hd], kr); }
+            t.c[kTallyPushes]++;
+        }
+        stop = granted < total || e == 0;  // out of excess
+    }
+    // the lane's share of the relabel candidate, as the dense step works it out from its nine arcs
+    StepOut o;
+    o.here = !has ? kNegInf : (adm ? (c - d > 0 ? key : kNegInf) : key);
+    o.stop = stop;
+    __builtin_amdgcn_wave_barrier();  // the record is read before the next step or item overwrites it
+    return o;
+}
+
 // One wave item.  A solo vertex keeps its excess in a register; a vertex split over
 // several items has its waves claim what they want to push from excess[u] and hand back
 // what was not granted.  `rot` permutes which lane owns which arcs, so that the prefix
 // order (= who gets the excess first) changes from round to round.
-__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int4 it, i64 S, unsigned rot, int par, Tally &t) {
+template <bool SOLO>
+__device__ __forceinline__ void push_item_t(const DevGraph &g, const HubAcc &hb, int2 *slive, int4 it, i64 S, unsigned rot, int par, Tally &t) {
     const int lane = lane_id();
     const int u = it.x;
     const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
-    const bool solo = it.w & 1;
-    const int seg1 = it.w >> 1;  // 1 + index of this hub segment's bound slots, 0: none
+    constexpr bool solo = SOLO;
+    const int seg1 = SOLO ? 0 : it.w >> 1;  // 1 + index of this hub segment's bound slots, 0: none (a solo item has none)
+    const unsigned plane = (unsigned)(lane + rot) & 63u;
     const i64 pu = g.price[u];
+    int cp[9];
+    if constexpr (SOLO) {
+        // The only item of its vertex: listed because it holds excess, and nobody else takes excess
+        // away, so nothing has to be known before the capacities of the first step are asked for.
+        // They travel with the vertex words; heads and costs follow for the lanes that found a
+        // residual arc (the rows of machines are mostly reverse arcs without flow).
+        load9(g.cap, r0 + plane * 8, min(r1, r0 + 512), r0 + 512 + plane, min(r1, r0 + kStep), cp);
+    }
     if (seg1) {
         // no residual arc of the segment has a key above the bound: with bound <= price[u] none is
         // admissible, and the bound stands in for the segment's relabel candidate
@@ -395,20 +458,36 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
     i64 e0 = __hip_atomic_load(&g.excess[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     e0 = __shfl(e0, 0);
     if (lane == 0) t.c[kTallyVisits]++;
-    if (e0 <= 0) {  // drained by the vertex's other items: this one stays unscanned
+    if (!SOLO && e0 <= 0) {  // drained by the vertex's other items: this one stays unscanned
         if (lane == 0) amax64(&g.cand[u], kInf);
         return;
     }
     i64 e = e0, best = kNegInf;
     bool incomplete = false;
-    const unsigned plane = (unsigned)(lane + rot) & 63u;
     for (unsigned h = r0; h < r1; h += kStep) {
         const unsigned a0 = h + plane * 8, lim8 = min(r1, h + 512), at = h + 512 + plane, limt = min(r1, h + kStep);
-        int cp[9], hd[9], cs[9];
-        load9(g.cap, a0, lim8, at, limt, cp);
-        load9(g.head, a0, lim8, at, limt, hd);
-        load9(g.cost, a0, lim8, at, limt, cs);
+        int hd[9], cs[9];
+        if (!SOLO || h != r0) load9(g.cap, a0, lim8, at, limt, cp);
         t.c[kTallyScans] += count9(a0, lim8, at, limt);
+        bool lane_live = true;
+        if constexpr (SOLO) {
+            unsigned lm = 0;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) lm |= (cp[j] > 0 ? 1u : 0u) << j;
+            lane_live = lm != 0;
+            const unsigned nl = (unsigned)__popc(lm), incl_l = wave_incl_scan_u32(nl), total_live = (unsigned)__shfl((int)incl_l, 63);
+            if (total_live <= 64u) {  // wave-uniform
+                const StepOut o = push_step_sparse(g, hb, slive, cp, lm, incl_l - nl, total_live, a0, at, h, pu, S, e, par, t);
+                best = o.here > best ? o.here : best;
+                if (o.stop) {
+                    if (h + kStep < r1) incomplete = true;
+                    break;
+                }
+                continue;
+            }
+        }
+        load9(g.head, a0, lim8, at, limt, hd, lane_live, h);
+        load9(g.cost, a0, lim8, at, limt, cs, lane_live, h);
         // Keys price[head] - cost * S are not kept per arc: what later steps need is which arcs are
         // admissible (a bit mask), the largest key of all live arcs and the largest key among the
         // live arcs that are not admissible.  If an admissible arc is still residual after the
@@ -511,6 +590,11 @@ __device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, i
     }
 }
 
+__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int2 *slive, int4 it, i64 S, unsigned rot, int par, Tally &t) {
+    if (it.w & 1) push_item_t<true>(g, hb, slive, it, S, rot, par, t);
+    else push_item_t<false>(g, hb, slive, it, S, rot, par, t);
+}
+
 __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     Ctrl *ct = g.ctrl;
     const unsigned *cnt = ct->list_cnt[k & 1];
@@ -525,6 +609,7 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
         if (i < kDbgCap) g.dbg[i] = make_int4(1, k, (int)nlow, (int)nseg);
     }
     __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
+    __shared__ int2 s_live[kBlock / 64][64];  // per wave: the residual arcs (index, capacity) of a sparse step
     const HubAcc hb{s_add, s_max};
     hub_init(hb, kNegInf);
     const i64 S = g.scale;
@@ -539,7 +624,7 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     for (unsigned i = wave; i < nseg; i += nwaves) {
         const int4 it = it_next;
         if (i + nwaves < nseg) it_next = segl[i + nwaves];  // on its way while this item is worked on
-        push_item(g, hb, it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t);
+        push_item(g, hb, s_live[threadIdx.x >> 6], it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t);
     }
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, hb, lowl[i], S, k & 1, t);
     hub_flush_push(g, hb, my_hub_vertex);
