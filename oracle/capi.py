@@ -90,12 +90,13 @@ def ssp(g):
 
 CS_EPS_PERCENTILE, CS_PRICE_REFINE, CS_COVER_SCALE = 1, 2, 4
 # The timed CPU baseline: the plain textbook variant (the one the parity tests use as the oracle)
-# and the tuned one (the GPU solver's first epsilon and alpha = 16, price refinement before each
-# later phase).  Arc fixing and push look-ahead are not implemented.
+# and the tuned ones (the GPU solver's first epsilon, price refinement before each later phase,
+# alpha = 16 or the GPU solver's 8).  Arc fixing and push look-ahead are not implemented.
 BASELINE_VARIANTS = {
     "plain (eps from max cost, alpha 12)": {},
     "tuned (eps from 90th-percentile cost, alpha 16, price refinement)": {"alpha": 16, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE},
-    "tuned + cost scale from the cycle-length bound (as the GPU solver)": {"alpha": 16, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE | CS_COVER_SCALE},
+    "tuned + cost scale from the cycle-length bound, alpha 16": {"alpha": 16, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE | CS_COVER_SCALE},
+    "tuned + cost scale from the cycle-length bound, alpha 8 (as the GPU solver)": {"alpha": 8, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE | CS_COVER_SCALE},
 }
 
 

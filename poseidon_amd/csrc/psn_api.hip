@@ -496,7 +496,7 @@ int psn_create(const psn_config *cfg, psn_ctx **out) {
     psn_ctx *c = new (std::nothrow) psn_ctx();
     if (!c) return PSN_ENOMEM;
     if (cfg) c->cfg = *cfg;
-    if (c->cfg.alpha_log2 <= 0 || c->cfg.alpha_log2 > 8) c->cfg.alpha_log2 = 4;
+    if (c->cfg.alpha_log2 <= 0 || c->cfg.alpha_log2 > 8) c->cfg.alpha_log2 = kDefaultAlphaLog2;
     c->rounds = c->cfg.rounds_per_batch > 0 ? c->cfg.rounds_per_batch : 12;
     if (const char *ev = std::getenv("PSN_ROUNDS")) c->rounds = std::max(1, std::min(64, atoi(ev)));  // tuning aid
     if (c->rounds & 1) ++c->rounds;  // list parity must be the same at every replay start
@@ -1139,7 +1139,10 @@ static Ctrl solve_init(psn_ctx *c, bool warm, const i64 *h_scalar) {
         // without costing more than the tails saved grows like the square root of the supply
         // (measured: about 20 units of 1 000, 60 of 10 000, 190 of 100 000).
         const i64 supply_units = h_scalar[kSupplyUnitsSlot];
-        i64 u = (i64)(kTailFactor * std::sqrt((double)std::max<i64>(0, supply_units)));
+        double tf = kTailFactor, tp = kTailPower;
+        if (const char *ev = std::getenv("PSN_TAIL_FACTOR")) tf = atof(ev);  // development: the law's two constants
+        if (const char *ev = std::getenv("PSN_TAIL_POWER")) tp = atof(ev);
+        i64 u = (i64)(tf * std::pow((double)std::max<i64>(0, supply_units), tp));
         if (const char *ev = std::getenv("PSN_TAIL_DIV")) u = supply_units / std::max(1, atoi(ev));  // tests: far more
         if (const char *ev = std::getenv("PSN_TAIL_UNITS")) u = std::max(0, atoi(ev));
         init.tail_units = (int)std::min<i64>(65534, u);
