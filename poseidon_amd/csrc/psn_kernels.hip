@@ -641,7 +641,6 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
 // workgroup, and one compute unit writes the ~4500 items of their segments several times
 // slower than the rest of the launch takes altogether.
 struct HubTurn { int v; bool act; unsigned r0, r1, nseg, first; int seg1; i64 e, c, p; };
-// every thread reads the same few words, so the turn needs no exchange inside the workgroup
 __device__ __forceinline__ HubTurn hub_fetch(const DevGraph &g, int hv) {
     HubTurn h;
     h.v = hv; h.e = g.excess[hv]; h.c = g.cand[hv]; h.p = g.price[hv];
@@ -650,23 +649,30 @@ __device__ __forceinline__ HubTurn hub_fetch(const DevGraph &g, int hv) {
 }
 constexpr int kCntUnits = 2;     // work-list counter slot: units of excess at the listed vertices (a vertex counts for at most 2^16 - 1)
 __device__ __forceinline__ unsigned excess_units(i64 e) { return e > 0 ? (unsigned)(e < 65535 ? e : 65535) : 0u; }
+// The thread that looks after a hub relabels it and resets its candidate.
 __device__ __forceinline__ void hub_decide(const DevGraph &g, HubTurn &h, bool do_relabel, i64 eps, unsigned rot, Tally &t, unsigned *cnt) {
     h.act = h.e > 0;
     h.nseg = (h.r1 - h.r0 + kWSeg - 1) / kWSeg;
     h.first = (rot ^ (unsigned)h.v * 0x9E3779B9u) % h.nseg;
-    if (threadIdx.x == 0) {
-        if (h.act) __hip_atomic_fetch_add(&cnt[kCntUnits], excess_units(h.e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (h.act && do_relabel && h.c != kInf && h.c != kNegInf && h.c <= h.p) { g.price[h.v] = h.c - eps; t.c[kTallyRelabels]++; }
-        const i64 nc = h.act ? kNegInf : kInf;
-        if (h.c != nc) g.cand[h.v] = nc;
-    }
+    if (h.act) __hip_atomic_fetch_add(&cnt[kCntUnits], excess_units(h.e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (h.act && do_relabel && h.c != kInf && h.c != kNegInf && h.c <= h.p) { g.price[h.v] = h.c - eps; t.c[kTallyRelabels]++; }
+    const i64 nc = h.act ? kNegInf : kInf;
+    if (h.c != nc) g.cand[h.v] = nc;
 }
-__device__ __forceinline__ void append_hub(const HubTurn &h, unsigned slot_base, int4 *segl) {
-    for (unsigned i = threadIdx.x; i < h.nseg; i += kBlock) {
-        unsigned sg = h.first + i;  // rotated order, as append_split
-        if (sg >= h.nseg) sg -= h.nseg;
-        const unsigned a = h.r0 + sg * kWSeg;
-        segl[slot_base + i] = make_int4(h.v, (int)a, (int)min(h.r1, a + kWSeg), (h.seg1 + (int)sg) << 1);
+// The hubs of a workgroup (hub slots blockIdx.x, blockIdx.x + gridDim.x, ...: one thread each) leave
+// their records in LDS; their segments take consecutive slots of the wave-item list.
+struct HubRec { int v, seg1; unsigned r0, r1, first, nseg, off; };  // nseg = 0: not active
+struct HubLds { HubRec rec[kMaxHubs]; unsigned total, base; };
+__device__ __forceinline__ void append_hubs(const HubLds &hl, unsigned count, unsigned slot_base, int4 *segl) {
+    const unsigned w = threadIdx.x >> 6, l = (unsigned)lane_id();
+    for (unsigned j = w; j < count; j += kBlock / 64) {  // a wave per hub, its lanes side by side
+        const HubRec h = hl.rec[j];
+        for (unsigned i = l; i < h.nseg; i += 64) {
+            unsigned sg = h.first + i;  // rotated order, as append_split
+            if (sg >= h.nseg) sg -= h.nseg;
+            const unsigned a = h.r0 + sg * kWSeg;
+            segl[slot_base + h.off + i] = make_int4(h.v, (int)a, (int)min(h.r1, a + kWSeg), (h.seg1 + (int)sg) << 1);
+        }
     }
 }
 
@@ -693,8 +699,10 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
         }
     };
     fetch((int)blockIdx.x * span);
-    // the hub of this workgroup: fetched with the control words as well
-    const int hub0 = (int)blockIdx.x < g.nhubs ? g.hub_vertex[blockIdx.x] : -1;
+    // the hubs of this workgroup, one per thread: their vertex is asked for with the control words as well
+    const int my_hs = (int)blockIdx.x + (int)threadIdx.x * (int)gridDim.x;
+    const bool have_hub = threadIdx.x < (unsigned)kMaxHubs && my_hs < g.nhubs;
+    const int hub_v = have_hub ? g.hub_vertex[my_hs] : -1;
     const unsigned *cnt = ct->list_cnt[k & 1];
     const int on = ct->rounds_on;
     const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg], epoch = ct->epoch;
@@ -706,15 +714,29 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
     const unsigned rot = mix32(epoch, (unsigned)k);
     Tally t;
     __shared__ AppendLds s_app;
-    __shared__ unsigned s_hub_base;
-    HubTurn hub{};
-    if (hub0 >= 0) hub = hub_fetch(g, hub0);  // decided below
-    int hub_state = hub0 >= 0 ? 1 : 0;  // 1: fetched, 2: dealt with
+    __shared__ HubLds s_hub;
+    const unsigned n_my_hubs = (int)blockIdx.x < g.nhubs ? min((unsigned)kMaxHubs, ((unsigned)g.nhubs - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0u;
+    if (n_my_hubs) {  // workgroup-uniform
+        HubTurn hub{};
+        if (have_hub) hub = hub_fetch(g, hub_v);
+        if (threadIdx.x == 0) s_hub.total = 0;
+        __syncthreads();
+        if (have_hub) {
+            hub_decide(g, hub, do_relabel, eps, rot, t, ct->list_cnt[dst]);
+            HubRec r;
+            r.v = hub.v; r.seg1 = hub.seg1; r.r0 = hub.r0; r.r1 = hub.r1; r.first = hub.first;
+            r.nseg = hub.act ? hub.nseg : 0u;
+            r.off = r.nseg ? __hip_atomic_fetch_add(&s_hub.total, r.nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            s_hub.rec[threadIdx.x] = r;
+        }
+        __syncthreads();
+    }
+    const unsigned hub_total = n_my_hubs ? s_hub.total : 0u;  // their slots ride on the sweep's own slot atomic
+    bool hubs_pending = n_my_hubs != 0;
     for (int base = blockIdx.x * span; base < g.n; base += gridDim.x * span) {
         if (base != (int)blockIdx.x * span) fetch(base);
         bool act[kVpt];
-        unsigned hub_segs = 0, hub_base = 0;  // the hub's slots ride on the sweep's own slot atomic
-        if (hub_state == 1) { hub_decide(g, hub, do_relabel, eps, rot, t, ct->list_cnt[dst]); hub_segs = hub.act ? hub.nseg : 0u; }
+        unsigned hub_base = 0;
 #pragma unroll
         for (int i = 0; i < kVpt; ++i) {
             act[i] = e[i] > 0 && seg1[i] == 0;  // not a hub (and inside the vertex range)
@@ -733,20 +755,13 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
             units = wave_sum_u32(units);
             if (lane_id() == 0 && units) __hip_atomic_fetch_add(&ct->list_cnt[dst][kCntUnits], units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app, hub_segs, &hub_base);
-        if (hub_state == 1) { if (hub.act) append_hub(hub, hub_base, g.list_seg[dst]); hub_state = 2; }
+        block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app, hubs_pending ? hub_total : 0u, &hub_base);
+        if (hubs_pending) { if (hub_total) append_hubs(s_hub, n_my_hubs, hub_base, g.list_seg[dst]); hubs_pending = false; }
     }
-    // hubs not dealt with above: this workgroup had no vertices to sweep, or the grid is smaller than the hub table
-    for (int hs = (int)blockIdx.x; hs < g.nhubs; hs += (int)gridDim.x) {
-        if (hs == (int)blockIdx.x && hub_state == 2) continue;
-        if (hs != (int)blockIdx.x) hub = hub_fetch(g, g.hub_vertex[hs]);
-        hub_decide(g, hub, do_relabel, eps, rot, t, ct->list_cnt[dst]);
-        if (hub.act) {  // workgroup-uniform
-            if (threadIdx.x == 0) s_hub_base = aadd32(&ct->list_cnt[dst][kClsSeg], hub.nseg);
-            __syncthreads();
-            append_hub(hub, s_hub_base, g.list_seg[dst]);
-        }
+    if (hubs_pending && hub_total) {  // this workgroup had no vertices to sweep: the hubs' slots are taken on their own
+        if (threadIdx.x == 0) s_hub.base = aadd32(&ct->list_cnt[dst][kClsSeg], hub_total);
         __syncthreads();
+        append_hubs(s_hub, n_my_hubs, s_hub.base, g.list_seg[dst]);
     }
     tally_flush<kTallyRelabels>(g, t);
 }
