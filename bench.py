@@ -305,35 +305,36 @@ def main():
             ts.eval_costs(cl, net)
             tr = ts.solve()
             kt = ts.kernel_times()
-        dom = "gu_expand"  # with the push sweep the largest share of a solve; the push sweep is reported beside it
-        dom_ms, dom_calls = kt[dom]
-        if dom_ms > 0 and dom_calls > 0:
-            bytes_total = algorithmic_bytes(tr, dom)
-            achieved = bytes_total / (dom_ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic("k_" + dom)
-            avg_us = dom_ms * 1e3 / dom_calls
-            roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        def sweep_roof(kind):
+            """One sweep kernel against the HBM roofline: the contract's bytes per unit of work over
+            its event-timed launches, what the PMC pass of the committed profile saw, and the
+            contract's figure with the arcs of which only the 4-byte capacity was read counted at 4 B."""
+            ms, calls = kt[kind]
+            if not (ms > 0 and calls > 0):
+                return None
+            bytes_total = algorithmic_bytes(tr, kind)
+            achieved = bytes_total / (ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic("k_" + kind)
+            avg_us = ms * 1e3 / calls
+            scans, skips = (tr.gu_arc_scans, tr.gu_arc_skips) if kind == "gu_expand" else (tr.arc_scans, tr.arc_skips)
+            real = bytes_total - 16 * skips
+            return {"bound": "hbm", "kernel": "k_" + kind, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from " + str(traffic_src),
-                    "launches": dom_calls, "avg_launch_us": round(avg_us, 2),
-                    "algorithmic_bytes_per_launch": int(bytes_total / dom_calls),
+                    "launches": calls, "avg_launch_us": round(avg_us, 2), "kernel_total_ms": round(ms, 2),
+                    "algorithmic_bytes_per_launch": int(bytes_total / calls),
                     # both currencies: the 20-bytes-per-arc-scan rule, and what HBM saw (PMC pass of the committed profile)
                     "achieved_contract": round(achieved, 1),
                     "achieved_hbm": round(traffic / (avg_us * 1e-6) / 1e9, 1) if traffic else None,
-                    "kernel_ms": {k: round(v[0], 2) for k, v in kt.items()}}
-            p_ms, p_calls = kt["push"]
-            if p_ms > 0 and p_calls > 0:
-                p_bytes = algorithmic_bytes(tr, "push")
-                p_traffic, _ = pmc_traffic("k_push")
-                roof["push_sweep"] = {"kernel": "k_push", "achieved": round(p_bytes / (p_ms * 1e-3) / 1e9, 1),
-                                      "frac": round(p_bytes / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "launches": p_calls,
-                                      "avg_launch_us": round(p_ms * 1e3 / p_calls, 2), "traffic": p_traffic,
-                                      "algorithmic_bytes_per_launch": int(p_bytes / p_calls)}
-            if dom == "gu_expand":
-                # steps of split rows in which no lane saw residual capacity read the 4-byte capacity only
-                real = 20 * (tr.gu_arc_scans - tr.gu_arc_skips) + 4 * tr.gu_arc_skips
-                roof["gu_arc_skips"] = tr.gu_arc_skips
-                roof["achieved_skips_at_4B"] = round(real / (dom_ms * 1e-3) / 1e9, 1)
+                    "arc_scans": scans, "arc_skips_read_at_4B": skips,
+                    "achieved_skips_at_4B": round(real / (ms * 1e-3) / 1e9, 1)}
+
+        # the dominant kernel is the sweep with the larger total over the solve; the other one rides beside it
+        sweeps = sorted(("push", "gu_expand"), key=lambda kd: -kt[kd][0])
+        roof = sweep_roof(sweeps[0])
+        if roof is not None:
+            roof["kernel_ms"] = {k: round(v[0], 2) for k, v in kt.items()}
+            roof["other_sweep"] = sweep_roof(sweeps[1])
         # ---- configs[3]: scheduler-service rounds, cold and warm after churn
         c3 = None
         if not args.no_c3 and world == 1:
@@ -380,7 +381,7 @@ def main():
             "solve_ms": round(solve_ms, 3), "solve_ms_min": round(min(solve_all), 3), "solve_ms_max": round(max(solve_all), 3),
             "optimal_cost": all_costs, "tasks_placed": placed_all,
             "upload_s_not_timed": round(upload_s, 4),
-            "counters": {"arc_scans": r.arc_scans, "gu_arc_scans": r.gu_arc_scans, "gu_arc_skips": r.gu_arc_skips, "sat_arc_scans": r.sat_arc_scans,
+            "counters": {"arc_scans": r.arc_scans, "gu_arc_scans": r.gu_arc_scans, "gu_arc_skips": r.gu_arc_skips, "arc_skips": r.arc_skips, "sat_arc_scans": r.sat_arc_scans,
                          "pushes": r.pushes, "relabels": r.relabels, "vertex_visits": r.vertex_visits, "rounds": r.rounds,
                          "gu_iterations": r.gu_iterations, "global_updates": r.global_updates, "refines": r.refines,
                          "launches": r.launches},

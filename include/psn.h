@@ -80,6 +80,8 @@ typedef struct psn_result {
     double solve_ms;         /* device time, first refine kernel -> cost readback */
     uint64_t gu_arc_skips;   /* of gu_arc_scans: arcs in 576-arc steps of split rows where no lane saw residual
                               * capacity, so only the 4-byte capacity word was read (not head, cost, distance) */
+    uint64_t arc_skips;      /* of arc_scans: arcs without residual capacity in rows whose residual arcs a push sweep
+                              * handed out one per lane; only their 4-byte capacity word was read */
 } psn_result;
 
 #define PSN_WARM_START 1u    /* psn_solve: keep prices and flow from the previous solve */

@@ -57,7 +57,7 @@ class Result(C.Structure):
                 ("vertex_visits", C.c_uint64), ("gu_arc_scans", C.c_uint64),
                 ("gu_relaxations", C.c_uint64), ("sat_arc_scans", C.c_uint64), ("rounds", C.c_uint64),
                 ("gu_iterations", C.c_uint64), ("global_updates", C.c_uint64), ("launches", C.c_uint64),
-                ("solve_ms", C.c_double), ("gu_arc_skips", C.c_uint64)]
+                ("solve_ms", C.c_double), ("gu_arc_skips", C.c_uint64), ("arc_skips", C.c_uint64)]
 
 
 class Layout(C.Structure):

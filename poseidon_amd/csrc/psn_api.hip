@@ -1211,6 +1211,7 @@ static void solve_report(psn_ctx *c, psn_result *out, int status, i64 cost, cons
     out->launches = (uint64_t)replays * (uint64_t)launches_per_replay;
     out->solve_ms = ms;
     out->gu_arc_skips = h_tally[kTallyGuSkips];
+    out->arc_skips = h_tally[kTallySkips];
     c->solved = status == PSN_OK;
 }
 

@@ -34,7 +34,7 @@ constexpr int PSN_EINFEASIBLE_DEV = -4;
 
 // tally slots (per wave, summed at the end of a solve)
 enum { kTallyScans = 0, kTallyPushes, kTallyRelabels, kTallyVisits, kTallyGuScans, kTallyGuRelax,
-       kTallySat, kTallyRounds, kTallyGuIters, kTallyGuSkips, kTallyN };
+       kTallySat, kTallyRounds, kTallyGuIters, kTallyGuSkips, kTallySkips, kTallyN };
 
 // Device-resident loop control.  k_begin (one thread) and the first thread of k_gu_apply are the
 // only writers of the flags; sweep kernels read them and return at once when their

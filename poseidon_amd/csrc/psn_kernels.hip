@@ -477,6 +477,7 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const HubAcc &hb,
             lane_live = lm != 0;
             const unsigned nl = (unsigned)__popc(lm), incl_l = wave_incl_scan_u32(nl), total_live = (unsigned)__shfl((int)incl_l, 63);
             if (total_live <= 64u) {  // wave-uniform
+                t.c[kTallySkips] += count9(a0, lim8, at, limt) - nl;
                 const StepOut o = push_step_sparse(g, hb, slive, cp, lm, incl_l - nl, total_live, a0, at, h, pu, S, e, par, t);
                 best = o.here > best ? o.here : best;
                 if (o.stop) {
@@ -629,7 +630,7 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, hb, lowl[i], S, k & 1, t);
     hub_flush_push(g, hb, my_hub_vertex);
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyRounds]++;
-    tally_flush<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds>(g, t);
+    tally_flush<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds, kTallySkips>(g, t);
 }
 
 // Relabel (optional) + rebuild of the active lists for the next round: one sweep over

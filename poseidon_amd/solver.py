@@ -28,6 +28,7 @@ class SolveResult:
     launches: int
     solve_ms: float
     gu_arc_skips: int = 0
+    arc_skips: int = 0
 
     @property
     def algorithmic_bytes(self) -> int:
