@@ -13,6 +13,7 @@
 // self-loops paired with themselves, capacity 0.  A task that arrives takes a free task
 // slot and one free place in its class row and in its job row: four arcs change.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstring>
@@ -963,42 +964,57 @@ int64_t psn_svc_schedule(psn_svc *s) {
         if (s->slot_used[(size_t)t]) members[(size_t)s->slot_task[(size_t)t]->cls].push_back(t);
     i64 placed = 0;
     std::vector<int32_t> final_place((size_t)s->P, -1);
-    std::vector<int> units(s->machines.size(), 0);  // units of the class on each machine; cleared through `touched`
-    std::vector<int> touched, rest;
-    std::vector<char> done;
-    for (int e = 0; e < s->E; ++e) {
-        const std::vector<int> &mem = members[(size_t)e];
-        i64 total = 0;
-        touched.clear();
-        for (int t : mem) {
-            const int m = place[(size_t)t];
-            if (m < 0) continue;
-            if ((size_t)m >= units.size()) return s->fail(PSN_EDEVICE, "placement names a machine that does not exist");
-            if (units[(size_t)m]++ == 0) touched.push_back(m);
-            ++total;
-        }
-        if (!total) continue;
-        done.assign(mem.size(), 0);
-        for (size_t i = 0; i < mem.size(); ++i) {  // keep what can be kept
-            const Task &tk = *s->slot_task[(size_t)mem[i]];
-            if (tk.machine < 0 || (size_t)tk.machine >= s->machines.size() || s->machines[(size_t)tk.machine].gen != tk.machine_gen) continue;
-            if (units[(size_t)tk.machine] == 0) continue;
-            --units[(size_t)tk.machine]; --total;
-            final_place[(size_t)mem[i]] = tk.machine;
-            done[i] = 1;
-        }
-        // the rest of the units, machine by machine, to the tasks the solver routed, then to any other
-        std::sort(touched.begin(), touched.end());
-        rest.clear();
-        for (int m : touched) { for (int c = 0; c < units[(size_t)m]; ++c) rest.push_back(m); units[(size_t)m] = 0; }
-        size_t ri = 0;
-        for (int pass = 0; pass < 2 && ri < rest.size(); ++pass)
-            for (size_t i = 0; i < mem.size() && ri < rest.size(); ++i) {
-                if (done[i]) continue;
-                if (pass == 0 && place[(size_t)mem[i]] < 0) continue;
-                final_place[(size_t)mem[i]] = rest[ri++];
+    // Classes are independent of each other here (a task belongs to one class and final_place is
+    // written per task), so a large cluster's classes are shared out over a few host threads.
+    std::atomic<int> next_class{0};
+    std::atomic<bool> bad_machine{false};
+    auto match_classes = [&]() {
+        std::vector<int> units(s->machines.size(), 0);  // units of the class on each machine; cleared through `touched`
+        std::vector<int> touched, rest;
+        std::vector<char> done;
+        for (int e = next_class.fetch_add(1); e < s->E; e = next_class.fetch_add(1)) {
+            const std::vector<int> &mem = members[(size_t)e];
+            i64 total = 0;
+            touched.clear();
+            for (int t : mem) {
+                const int m = place[(size_t)t];
+                if (m < 0) continue;
+                if ((size_t)m >= units.size()) { bad_machine = true; return; }
+                if (units[(size_t)m]++ == 0) touched.push_back(m);
+                ++total;
+            }
+            if (!total) continue;
+            done.assign(mem.size(), 0);
+            for (size_t i = 0; i < mem.size(); ++i) {  // keep what can be kept
+                const Task &tk = *s->slot_task[(size_t)mem[i]];
+                if (tk.machine < 0 || (size_t)tk.machine >= s->machines.size() || s->machines[(size_t)tk.machine].gen != tk.machine_gen) continue;
+                if (units[(size_t)tk.machine] == 0) continue;
+                --units[(size_t)tk.machine]; --total;
+                final_place[(size_t)mem[i]] = tk.machine;
                 done[i] = 1;
             }
+            // the rest of the units, machine by machine, to the tasks the solver routed, then to any other
+            std::sort(touched.begin(), touched.end());
+            rest.clear();
+            for (int m : touched) { for (int c = 0; c < units[(size_t)m]; ++c) rest.push_back(m); units[(size_t)m] = 0; }
+            size_t ri = 0;
+            for (int pass = 0; pass < 2 && ri < rest.size(); ++pass)
+                for (size_t i = 0; i < mem.size() && ri < rest.size(); ++i) {
+                    if (done[i]) continue;
+                    if (pass == 0 && place[(size_t)mem[i]] < 0) continue;
+                    final_place[(size_t)mem[i]] = rest[ri++];
+                    done[i] = 1;
+                }
+        }
+    };
+    {
+        // (a cold round has nothing to keep: its matching is too short to be worth the threads' start)
+        const int helpers = warm && s->P >= 20000 && s->E >= 8 ? 3 : 0;
+        std::vector<std::thread> pool;
+        for (int i = 0; i < helpers; ++i) pool.emplace_back(match_classes);
+        match_classes();
+        for (std::thread &th : pool) th.join();
+        if (bad_machine) return s->fail(PSN_EDEVICE, "placement names a machine that does not exist");
     }
     // Keep-running mode: a placement is admitted only if the task's request still fits next to what
     // the machine already holds, tasks admitted earlier in this round included.  One class never
