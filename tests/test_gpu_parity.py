@@ -216,6 +216,8 @@ def test_synthetic_clusters_vs_golden_and_oracle(solver, cfg, seed):
     r = solver.solve()
     gold = _gold(cfg, seed)
     assert r.total_cost == gold["optimal_cost"]
+    # work counters: machine rows go through the push sweep's sparse step (most of their arcs carry no flow)
+    assert 0 < r.arc_skips < r.arc_scans and r.gu_arc_skips <= r.gu_arc_scans
     resid, price = solver.residual(), solver.prices()
     assert capi.check(og, resid, price, scale=solver.price_scale())[:2] == (0, r.total_cost)
     # K5: every placed task sits on a machine that its class can use, within slot capacity
