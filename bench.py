@@ -148,8 +148,8 @@ def service_rounds(config_id, seed, device, churn_rounds=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, help="psn-synth-v1 config id (2 = 10k machines / 100k pods)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-graphs", type=int, default=256,
