@@ -529,11 +529,11 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const HubAcc &hb,
             }
             i64 mine = granted - (incl - want);  // what this lane may push
             if (mine > 0) {
-                // two batches (slots 0-4, 5-8): amounts first, then every load of the batch before any
-                // dependent store
+                // three batches of three slots (twelve registers less than two of five and four): amounts
+                // first, then every load of the batch before any dependent store
 #pragma unroll
-                for (int b0 = 0; b0 < 9; b0 += 5) {
-                    constexpr int W = 5;
+                for (int b0 = 0; b0 < 9; b0 += 3) {
+                    constexpr int W = 3;
                     int d[W], rv[W], cr[W], hub[W];
 #pragma unroll
                     for (int x = 0; x < W; ++x) {
