@@ -1136,8 +1136,9 @@ static Ctrl solve_init(psn_ctx *c, bool warm, const i64 *h_scalar) {
     {
         // Phases other than the last stop when little excess is left on its way (see k_begin).  The
         // last phase has to route what they leave, one bounce after the other; how much it takes
-        // without costing more than the tails saved grows like the square root of the supply
-        // (measured: about 20 units of 1 000, 60 of 10 000, 190 of 100 000).
+        // without costing more than the tails saved grows a little faster than the square root of
+        // the supply (measured with phases that step by 8: about 20 units of 1 000, 60-95 of 10 000,
+        // 350-450 of 100 000).
         const i64 supply_units = h_scalar[kSupplyUnitsSlot];
         double tf = kTailFactor, tp = kTailPower;
         if (const char *ev = std::getenv("PSN_TAIL_FACTOR")) tf = atof(ev);  // development: the law's two constants
