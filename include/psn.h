@@ -35,7 +35,8 @@ extern "C" {
 #define PSN_ENOMEM (-2)      /* host or device allocation failed */
 #define PSN_EDEVICE (-3)     /* HIP runtime error (see psn_last_error) */
 #define PSN_EINFEASIBLE (-4) /* supplies cannot be routed */
-#define PSN_EOVERFLOW (-5)   /* cost * (n+1) * bound does not fit int64 */
+#define PSN_EOVERFLOW (-5)   /* 8 n (n+1) max|cost| > 4e18: scaled prices might not fit int64 (the cost scale
+                              * is 2|C|+1 for a vertex cover C, n+1 at most; the check assumes the worst) */
 #define PSN_ESTATE (-6)      /* call out of order (e.g. solve before upload) */
 #define PSN_ELIMIT (-7)      /* iteration guard tripped without convergence */
 
@@ -82,6 +83,9 @@ typedef struct psn_result {
                               * capacity, so only the 4-byte capacity word was read (not head, cost, distance) */
     uint64_t arc_skips;      /* of arc_scans: arcs without residual capacity in rows whose residual arcs a push sweep
                               * handed out one per lane; only their 4-byte capacity word was read */
+    int32_t warm_started;    /* 1: the solve resumed from the kept flow and prices; 0: it started cold (no
+                              * PSN_WARM_START, nothing solved before, or an update invalidated the kept state) */
+    int32_t mirrored_replays; /* replays run on the reversed network (deficits pushed towards the excesses) */
 } psn_result;
 
 #define PSN_WARM_START 1u    /* psn_solve: keep prices and flow from the previous solve */
@@ -251,14 +255,15 @@ int psn_get_placements(psn_ctx *ctx, const psn_layout *layout, int32_t *task_to_
  * context's GPU, e.g. the send buffer of an all-gather; returns after the copy is done. */
 int psn_get_placements_device(psn_ctx *ctx, const psn_layout *layout, void *dst_device);
 
-/* psn_get_placements_device for callers that cannot allocate (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc): same result into the same kind of
+/* psn_get_placements_device for callers that cannot allocate (tight serving loops, harnesses
+ * that forbid hipMalloc): same result into the same kind of
  * caller-owned device buffer, but the per-class unit lists the extraction kernel needs live in a
  * fixed 4 MiB device array that every GPU the library runs on holds from the first psn_create
  * on it until the process ends, and the call makes no device or host allocation of any kind.
  * Limit: n_classes * n_tasks <= 1 048 576 (PSN_EINVAL beyond it, nothing launched).  All
  * contexts of one GPU share that array: calls that overlap on one GPU race, the caller
- * serialises them.  This entry point has no counterpart in the reference. */
+ * serialises them.  The call waits for its stream (it reads back the kernel's layout verdict), so it
+ * cannot itself run under HIP stream capture.  This entry point has no counterpart in the reference. */
 int psn_get_placements_device_noalloc(psn_ctx *ctx, const psn_layout *layout, void *dst_device);
 
 /* Placements of `count` solved contexts into one buffer, row i (int32, `stride` entries apart,

@@ -64,6 +64,10 @@ int psn_dimacs_write(const char *path, int32_t n, int64_t m2, const int64_t *row
 int psn_dimacs_size(const char *path, int32_t *n, int64_t *m);
 int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32_t *head, int32_t *cap,
                     int32_t *cost, int64_t *supply, int64_t *base_cost);
+/* The same, also returning the lower bound each arc had in the file (low[m], file order).  Lines
+ * longer than 510 characters are refused (PSN_EINVAL) by every reader here. */
+int psn_dimacs_read_lower(const char *path, int32_t n, int64_t m, int32_t *tail, int32_t *head, int32_t *cap,
+                          int32_t *cost, int64_t *supply, int64_t *base_cost, int32_t *low);
 
 /* Change records: a second file that edits a problem already read, so that the resident network
  * can be edited in place and the solve warm-started: a later scheduling round described as changes
@@ -79,6 +83,14 @@ int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32
 int psn_dimacs_changes_size(const char *path, int64_t *n_arc_changes, int64_t *n_supply_changes);
 int psn_dimacs_read_changes(const char *path, int32_t n, int64_t m, const int32_t *tail, const int32_t *head,
                             int64_t *arc, int32_t *new_cap, int32_t *new_cost, int32_t *vertex, int64_t *new_supply);
+/* The same with the lower bounds psn_dimacs_read_lower returned: an `x` record that targets an arc
+ * whose lower bound in the problem file was not 0 is PSN_EINVAL (the reader folded that bound
+ * into the capacity, the supplies and the base cost; a record that only carries a new upper bound
+ * and cost cannot be applied to it).  psn_dimacs_read_changes cannot tell and applies the record
+ * as if the bound had been 0: use it only for problems without lower bounds. */
+int psn_dimacs_read_changes_lower(const char *path, int32_t n, int64_t m, const int32_t *tail, const int32_t *head,
+                                  const int32_t *low, int64_t *arc, int32_t *new_cap, int32_t *new_cost,
+                                  int32_t *vertex, int64_t *new_supply);
 
 /* FNV-1a-64 over a byte range, chained through h (start with 0xCBF29CE484222325). */
 uint64_t psn_fnv1a64(const void *data, int64_t nbytes, uint64_t h);

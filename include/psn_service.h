@@ -82,6 +82,11 @@ typedef struct psn_svc_config {
                                   /root/reference/cmd/poseidon/poseidon.go:52-63).  1: every runnable task
                                   is re-optimised in every round and may be migrated or preempted (what-if
                                   and defragmentation runs; the incremental benchmark configuration). */
+    int32_t stats_utilization; /* how psn_svc_add_node_stats_raw reads a utilisation figure: 1 always as a
+                                  fraction of the capacity (/root/reference/pkg/firmament/resource_stats.proto:36-39,56-59),
+                                  2 always as an absolute quantity (what /root/reference/pkg/stats/stats_test.go:100-127
+                                  carries), 0 (default) by value: up to 1.0 a fraction, above it a quantity -
+                                  ambiguous for absolute readings of at most one unit */
     psn_config solver;         /* passed to psn_create (device field overwritten) */
 } psn_svc_config;
 

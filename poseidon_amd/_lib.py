@@ -35,7 +35,7 @@ EXPORTS = [
     "psn_svc_add_node_stats", "psn_svc_check", "psn_svc_schedule", "psn_svc_get_deltas", "psn_svc_get_stats",
     "psn_svc_task_submitted_sel", "psn_svc_node_labels", "psn_svc_export_mask", "psn_svc_network_size", "psn_svc_export_network", "psn_svc_task_placement", "psn_svc_solver",
     "psn_gather_placements", "psn_debug_alloc_count", "psn_get_placements_device_noalloc", "psn_price_scale", "psn_update_costs",
-    "psn_dimacs_changes_size", "psn_dimacs_read_changes",
+    "psn_dimacs_changes_size", "psn_dimacs_read_changes", "psn_dimacs_read_lower", "psn_dimacs_read_changes_lower",
     "psn_svc_add_node_stats_raw", "psn_svc_add_task_stats_raw", "psn_build_network_device", "psn_get_structure", "psn_get_rows", "psn_build_network_rooms_device",
 ]
 
@@ -57,7 +57,8 @@ class Result(C.Structure):
                 ("vertex_visits", C.c_uint64), ("gu_arc_scans", C.c_uint64),
                 ("gu_relaxations", C.c_uint64), ("sat_arc_scans", C.c_uint64), ("rounds", C.c_uint64),
                 ("gu_iterations", C.c_uint64), ("global_updates", C.c_uint64), ("launches", C.c_uint64),
-                ("solve_ms", C.c_double), ("gu_arc_skips", C.c_uint64), ("arc_skips", C.c_uint64)]
+                ("solve_ms", C.c_double), ("gu_arc_skips", C.c_uint64), ("arc_skips", C.c_uint64),
+                ("warm_started", C.c_int32), ("mirrored_replays", C.c_int32)]
 
 
 class Layout(C.Structure):
@@ -97,6 +98,8 @@ def load_library():
     lib.psn_update_costs.argtypes = [vp, i64, vp, vp]
     lib.psn_dimacs_changes_size.argtypes = [C.c_char_p, C.POINTER(i64), C.POINTER(i64)]
     lib.psn_dimacs_read_changes.argtypes = [C.c_char_p, i32, i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.psn_dimacs_read_changes_lower.argtypes = [C.c_char_p, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.psn_dimacs_read_lower.argtypes = [C.c_char_p, i32, i64, vp, vp, vp, vp, vp, C.POINTER(i64), vp]
     lib.psn_solve.argtypes = [vp, u32, C.POINTER(Result)]
     lib.psn_solve_batch.argtypes = [vp, i32, u32, i32, vp]
     lib.psn_get_flow.argtypes = [vp, vp]

@@ -24,6 +24,13 @@ def padded_share(n_graphs: int, world: int) -> int:
     return (n_graphs + world - 1) // world
 
 
+def graph_order(n_graphs: int, world: int) -> List[int]:
+    """Row of a rank-major gathered buffer (world blocks of padded_share rows, rank r's row i being
+    graph r + i * world) that holds graph b, for b = 0 .. n_graphs - 1."""
+    share = padded_share(n_graphs, world)
+    return [(b % world) * share + b // world for b in range(n_graphs)]
+
+
 def all_gather_placements(local: torch.Tensor, n_graphs: int, world: int, rank: int, group=None) -> torch.Tensor:
     """local: int32 [len(shard), P] placements of this rank's graphs (graph-id order).
     Returns int32 [n_graphs, P] in graph-id order on every rank."""

@@ -82,6 +82,11 @@ struct psn_ctx {
     unsigned *d_pull_cnt = nullptr;
     long long cover_size = 0, cover_cap = 0;
     struct GroupCache *gcache = nullptr;  // lockstep group led by this context, kept between batch calls
+    // the slot-block layout the cost kernel last verified on the device (k_check_slot_layout re-reads
+    // the pairing of every slot arc: 150 MB at 10 000 machines): valid for this upload until arcs are patched
+    unsigned long long layout_ok_gen = ~0ull;
+    int layout_ok_E = 0, layout_ok_N = 0, layout_ok_K = 0;
+    std::vector<int64_t> layout_ok_base;
 };
 
 namespace {
@@ -229,7 +234,10 @@ int build_graph(psn_ctx *c) {
     if (c->cfg.flags & PSN_CFG_EAGER) return PSN_OK;
     HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     enqueue_replay(c, c->stream);
-    HIPCHK(c, hipStreamEndCapture(c->stream, &c->graph));
+    const hipError_t e_launch = hipGetLastError();
+    const hipError_t e_end = hipStreamEndCapture(c->stream, &c->graph);  // always, so that the stream leaves capture mode
+    HIPCHK(c, e_launch);
+    HIPCHK(c, e_end);
     HIPCHK(c, hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0));
     return PSN_OK;
 }
@@ -903,8 +911,12 @@ static int eval_costs_impl(psn_ctx *c, const psn_layout *lay, const int64_t *cap
         const long long total = 2LL * E * N;
         const int grid = (int)std::min<long long>((total + kBlock - 1) / kBlock, 8192);
         const i64 *d_base = d + 4 * (size_t)N + 2 * (size_t)E;
-        // the layout pass writes nothing but its counter; the cost kernel returns at once when it is nonzero
-        hipLaunchKernelGGL(k_check_slot_layout, dim3(std::max(1, grid / 2)), dim3(kBlock), 0, c->stream, c->g, E, N, K, d_base, d_bad);
+        // the layout pass writes nothing but its counter; the cost kernel returns at once when it is nonzero.
+        // A layout that passed once stands until the network is uploaded again or arcs are rewired.
+        const bool verified = c->layout_ok_gen == c->upload_gen && c->layout_ok_E == E && c->layout_ok_N == N && c->layout_ok_K == K &&
+                              c->layout_ok_base.size() == (size_t)E && std::equal(ec_arc_base, ec_arc_base + E, c->layout_ok_base.begin());
+        if (!verified)
+            hipLaunchKernelGGL(k_check_slot_layout, dim3(std::max(1, grid / 2)), dim3(kBlock), 0, c->stream, c->g, E, N, K, d_base, d_bad);
         hipLaunchKernelGGL(k_eval_costs, dim3(grid), dim3(kBlock), 0, c->stream, c->g, E, N, K, d, d + N, d + 2 * (size_t)N,
                            d + 3 * (size_t)N, d + 4 * (size_t)N, d + 4 * (size_t)N + E, d_base, c->d_cost,
                            c->d_ocap, keep_flow, c->allow_on ? c->d_allow : nullptr, c->allow_words, d_bad);
@@ -915,6 +927,8 @@ static int eval_costs_impl(psn_ctx *c, const psn_layout *lay, const int64_t *cap
     if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_eval_costs", e);
     if (c->h_flag[0])  // nothing was written: the resident network and its solved state stand as they were
         return fail(c, PSN_EINVAL, "slot arcs and their reverse arcs do not pair up class-major, slot-minor at the start of the machine rows");
+    c->layout_ok_gen = c->upload_gen; c->layout_ok_E = E; c->layout_ok_N = N; c->layout_ok_K = K;
+    c->layout_ok_base.assign(ec_arc_base, ec_arc_base + E);
     if (!keep_flow) c->solved = false;  // the flow on re-priced arcs was reset
     return PSN_OK;
 }
@@ -986,7 +1000,8 @@ int psn_patch_arcs(psn_ctx *c, int64_t count, const int64_t *arc_index, const in
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(c->h_flag, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && launch_cover(c) != PSN_OK) return PSN_EDEVICE;  // rewired arcs may have grown the vertex cover
+    c->layout_ok_gen = ~0ull;  // pairings change: the slot-block layout is verified again by the next pricing
+    if (e == hipSuccess) { const int rcl = launch_cover(c); if (rcl != PSN_OK) return rcl; }  // rewired arcs may have grown the vertex cover (the error text is launch_cover's)
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_patch_arcs", e);
     bad = c->h_flag[0];
@@ -1195,7 +1210,8 @@ static int solve_finish(psn_ctx *c, hipStream_t s, i64 *h_cost, unsigned long lo
     return PSN_OK;
 }
 static void solve_report(psn_ctx *c, psn_result *out, int status, i64 cost, const unsigned long long *h_tally, long long replays,
-                         int launches_per_replay, float ms) {
+                         int launches_per_replay, float ms, bool warm) {
+    out->warm_started = warm ? 1 : 0;
     out->total_cost = cost;
     out->status = status;
     out->refines = (int32_t)c->h_ctrl->tally_refines;
@@ -1303,7 +1319,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     HIPCHK(c, hipStreamSynchronize(s));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    solve_report(c, out, status, h_cost, h_tally, replays, c->launches_per_replay, ms);
+    solve_report(c, out, status, h_cost, h_tally, replays, c->launches_per_replay, ms, warm);
     if (std::getenv("PSN_DEBUG_SOLVE"))
         fprintf(stderr, "psn_solve: %s first shift %d (max violation %lld) refines %d replays %lld rounds %llu gus %llu gu_iters %llu pushes %llu relabels %llu %.2f ms\n",
                 warm ? "warm" : "cold", ceil_log2(std::max<i64>(1, warm ? h_scalar[1] : h_scalar[2] * g.scale)) - c->cfg.alpha_log2, (long long)h_scalar[1], out->refines, replays,
@@ -1408,7 +1424,9 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
     int rc = PSN_OK;
     long long replays = 0;
     float ms = 0.f;
-#define GCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { drop_group_cache(lead); return fail(lead, PSN_EDEVICE, #call, e_); } } while (0)
+    // On a failed call: the stream is drained first (copies into the cache's pinned blocks may still be in
+    // flight), then the cache goes, then the error is reported against the group's first member.
+#define GCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipStreamSynchronize(s); drop_group_cache(lead); return fail(lead, PSN_EDEVICE, #call, e_); } } while (0)
     const bool dbg_t = std::getenv("PSN_DEBUG_GROUP") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_a = now(), t_b = 0, t_c = 0, t_d = 0, t_e = 0;
@@ -1472,8 +1490,11 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
     t_b = now();
     if (fresh) {
         GCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        group_enqueue_replay(m, gc->d_graphs, gc->d_status, s, &gc->launches);
-        GCHK(hipStreamEndCapture(s, &gc->graph));  // ends the capture whether or not it yields a graph
+        const int rce = group_enqueue_replay(m, gc->d_graphs, gc->d_status, s, &gc->launches);
+        const hipError_t e_launch = hipGetLastError();  // a launch the capture refused
+        const hipError_t e_end = hipStreamEndCapture(s, &gc->graph);  // always: the stream must leave capture mode before anything else runs on it
+        if (rce != PSN_OK || e_launch != hipSuccess) GCHK(e_launch != hipSuccess ? e_launch : hipErrorUnknown);
+        GCHK(e_end);
         GCHK(hipGraphInstantiate(&gc->gexec, gc->graph, nullptr, nullptr, 0));
     }
     t_c = now();
@@ -1528,7 +1549,7 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
     if (dbg_t) fprintf(stderr, "group of %zu (%s): prepare %.2f capture+instantiate %.2f replays(%lld) %.2f finish %.2f ms\n", G, fresh ? "new" : "cached", t_b - t_a, t_c - t_b, replays, t_d - t_c, t_e - t_d);
     rc = PSN_OK;
     for (size_t i = 0; i < G; ++i) {
-        solve_report(m[i], out[i], status[i], h_cost[i], &h_tally[i * kTallyN], replays, gc->launches, ms);
+        solve_report(m[i], out[i], status[i], h_cost[i], &h_tally[i * kTallyN], replays, gc->launches, ms, warm[i] != 0);
         if (status[i] != PSN_OK) {
             (void)fail(m[i], status[i], h_scalar[i * kScalarSlots + kSupplySumSlot] != 0 ? "supplies do not sum to zero" : "solve did not converge");
             if (rc == PSN_OK) rc = status[i];

@@ -61,7 +61,7 @@ struct Ctrl {
 struct DevGraph {
     int n;
     unsigned m2;
-    i64 scale;  // S = n + 1
+    i64 scale;  // S = 2 |C| + 1, C a vertex cover (at most n + 1); negative while the reversed network is being worked on
     const unsigned *row;
     const int *head, *cost, *rev, *tail, *ocap;
     const unsigned char *cls;  // class | kClsLean

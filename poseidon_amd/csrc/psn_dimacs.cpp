@@ -14,6 +14,20 @@
 #include "../../include/psn.h"
 #include "../../include/psn_builder.h"
 
+namespace {
+// One line of at most 510 characters; a longer one is refused rather than split (its tail would be
+// parsed as a record of its own).  1: a line was read, 0: end of file, -1: over-long line.
+int read_line(FILE *f, char *line, size_t size) {
+    if (!std::fgets(line, (int)size, f)) return 0;
+    const size_t len = std::strlen(line);
+    if (len + 1 == size && line[len - 1] != '\n') {
+        const int c = std::fgetc(f);
+        if (c != EOF) return -1;
+    }
+    return 1;
+}
+}  // namespace
+
 extern "C" {
 
 int psn_csr_from_arcs(int32_t n, int64_t m, const int32_t *tail, const int32_t *head, const int32_t *cap, const int32_t *cost,
@@ -61,7 +75,7 @@ int psn_dimacs_size(const char *path, int32_t *n, int64_t *m) {
     if (!f) return PSN_EINVAL;
     char line[512];
     int rc = PSN_EINVAL;
-    while (std::fgets(line, sizeof line, f)) {
+    while (read_line(f, line, sizeof line) == 1) {
         if (line[0] != 'p') continue;
         long long nn = 0, mm = 0;
         char kind[16] = {0};
@@ -74,8 +88,8 @@ int psn_dimacs_size(const char *path, int32_t *n, int64_t *m) {
     return rc;
 }
 
-int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32_t *head, int32_t *cap, int32_t *cost,
-                    int64_t *supply, int64_t *base_cost) {
+static int dimacs_read_impl(const char *path, int32_t n, int64_t m, int32_t *tail, int32_t *head, int32_t *cap, int32_t *cost,
+                            int64_t *supply, int64_t *base_cost, int32_t *low) {
     if (!path || n <= 0 || m < 0 || !supply || (m > 0 && (!tail || !head || !cap || !cost))) return PSN_EINVAL;
     FILE *f = std::fopen(path, "r");
     if (!f) return PSN_EINVAL;
@@ -83,8 +97,9 @@ int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32
     std::vector<int64_t> shift((size_t)n, 0);  // supply moved by lower bounds; added at the end, whatever order the lines come in
     int64_t base = 0, got = 0;
     char line[512];
-    int rc = PSN_OK;
-    while (rc == PSN_OK && std::fgets(line, sizeof line, f)) {
+    int rc = PSN_OK, lr = 0;
+    while (rc == PSN_OK && (lr = read_line(f, line, sizeof line)) != 0) {
+        if (lr < 0) { rc = PSN_EINVAL; break; }
         if (line[0] == 'n') {
             long long v = 0, s = 0;
             if (std::sscanf(line, "n %lld %lld", &v, &s) != 2 || v < 1 || v > n) rc = PSN_EINVAL;
@@ -96,6 +111,7 @@ int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32
             // a lower bound is flow that must be there: route it up front
             shift[(size_t)(u - 1)] -= lo; shift[(size_t)(v - 1)] += lo; base += lo * c;
             tail[got] = (int32_t)(u - 1); head[got] = (int32_t)(v - 1); cap[got] = (int32_t)(hi - lo); cost[got] = (int32_t)c;
+            if (low) low[got] = (int32_t)std::min<long long>(lo, INT32_MAX);
             ++got;
         }
     }
@@ -104,6 +120,16 @@ int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32
     for (int32_t v = 0; v < n; ++v) supply[v] += shift[(size_t)v];
     if (base_cost) *base_cost = base;
     return rc;
+}
+
+int psn_dimacs_read(const char *path, int32_t n, int64_t m, int32_t *tail, int32_t *head, int32_t *cap, int32_t *cost,
+                    int64_t *supply, int64_t *base_cost) {
+    return dimacs_read_impl(path, n, m, tail, head, cap, cost, supply, base_cost, nullptr);
+}
+int psn_dimacs_read_lower(const char *path, int32_t n, int64_t m, int32_t *tail, int32_t *head, int32_t *cap, int32_t *cost,
+                          int64_t *supply, int64_t *base_cost, int32_t *low) {
+    if (m > 0 && !low) return PSN_EINVAL;
+    return dimacs_read_impl(path, n, m, tail, head, cap, cost, supply, base_cost, low);
 }
 
 // ---- change records: a second file that edits a problem already read
@@ -118,8 +144,9 @@ int parse_changes(const char *path, std::vector<ChangeLine> &out) {
     FILE *f = std::fopen(path, "r");
     if (!f) return PSN_EINVAL;
     char line[512];
-    int rc = PSN_OK;
-    while (rc == PSN_OK && std::fgets(line, sizeof line, f)) {
+    int rc = PSN_OK, lr = 0;
+    while (rc == PSN_OK && (lr = read_line(f, line, sizeof line)) != 0) {
+        if (lr < 0) { rc = PSN_EINVAL; break; }
         ChangeLine ch{};
         if (line[0] == 'x') {
             ch.kind = 'x';
@@ -150,8 +177,8 @@ int psn_dimacs_changes_size(const char *path, int64_t *n_arc_changes, int64_t *n
     return PSN_OK;
 }
 
-int psn_dimacs_read_changes(const char *path, int32_t n, int64_t m, const int32_t *tail, const int32_t *head, int64_t *arc,
-                            int32_t *new_cap, int32_t *new_cost, int32_t *vertex, int64_t *new_supply) {
+static int read_changes_impl(const char *path, int32_t n, int64_t m, const int32_t *tail, const int32_t *head, const int32_t *low, int64_t *arc,
+                             int32_t *new_cap, int32_t *new_cost, int32_t *vertex, int64_t *new_supply) {
     if (!path || n <= 0 || m < 0 || (m > 0 && (!tail || !head))) return PSN_EINVAL;
     std::vector<ChangeLine> ch;
     int rc = parse_changes(path, ch);
@@ -172,9 +199,21 @@ int psn_dimacs_read_changes(const char *path, int32_t n, int64_t m, const int32_
         const uint64_t want = ((uint64_t)(uint32_t)(c.a - 1) << 32) | (uint32_t)(c.b - 1);
         auto it = std::lower_bound(order.begin(), order.end(), want, [&](int64_t i, uint64_t w) { return key(i) < w; });
         if (it == order.end() || key(*it) != want || (order.end() - it) <= c.k || key(*(it + c.k)) != want) return PSN_EINVAL;  // no such arc
+        // An arc whose lower bound the reader folded away (capacity hi - lo, lo units moved into the
+        // supplies and the base cost) cannot be edited by a record that only carries the new upper
+        // bound and cost: the residual capacity and the base cost would both come out wrong.
+        if (low && low[*(it + c.k)] != 0) return PSN_EINVAL;
         arc[na] = *(it + c.k); new_cap[na] = (int32_t)c.hi; new_cost[na] = (int32_t)c.c; ++na;
     }
     return PSN_OK;
+}
+int psn_dimacs_read_changes(const char *path, int32_t n, int64_t m, const int32_t *tail, const int32_t *head, int64_t *arc,
+                            int32_t *new_cap, int32_t *new_cost, int32_t *vertex, int64_t *new_supply) {
+    return read_changes_impl(path, n, m, tail, head, nullptr, arc, new_cap, new_cost, vertex, new_supply);
+}
+int psn_dimacs_read_changes_lower(const char *path, int32_t n, int64_t m, const int32_t *tail, const int32_t *head, const int32_t *low,
+                                  int64_t *arc, int32_t *new_cap, int32_t *new_cost, int32_t *vertex, int64_t *new_supply) {
+    return read_changes_impl(path, n, m, tail, head, low, arc, new_cap, new_cost, vertex, new_supply);
 }
 
 }  // extern "C"

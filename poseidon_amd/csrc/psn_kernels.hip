@@ -11,7 +11,8 @@
 //                  admissible under one price vector), excess moves by 64-bit atomics.
 //   relabel phase  residual graph frozen; an active vertex whose scan found no
 //                  admissible residual arc gets price = max(price[v] - cost) - eps.
-// Epsilon is a power of two; costs are multiplied by S = n + 1, so eps = 1 is optimal.
+// Epsilon is a power of two; costs are multiplied by S = 2 |C| + 1 for a vertex cover C of the
+// network (a simple residual cycle has at most 2 |C| arcs), so a flow that is 1-optimal is optimal.
 // All loop control (epsilon schedule, when to saturate, when to run a global price
 // update, termination) lives in a device-resident Ctrl block that tiny single-thread
 // kernels advance, so one hipGraph can be replayed until Ctrl.done is set.

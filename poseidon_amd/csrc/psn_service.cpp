@@ -504,6 +504,8 @@ struct psn_svc {
     void refresh_external() {
         ext_cpu.assign(machines.size(), 0); ext_mem.assign(machines.size(), 0);
         std::vector<i64> own_cpu, own_mem;
+        any_measured = false;  // a measurement may have been replaced by a plain usage figure since
+        for (const Machine &mc : machines) any_measured = any_measured || mc.meas_cpu >= 0 || mc.meas_mem >= 0;
         if (any_measured) {
             own_cpu.assign(machines.size(), 0); own_mem.assign(machines.size(), 0);
             for (auto &kv : tasks) {
@@ -716,10 +718,14 @@ int psn_svc_add_node_stats(psn_svc *s, const char *uuid, int64_t used_cpu, int64
 // A utilisation figure of ResourceStats as a quantity: the message describes it as a fraction of the
 // capacity (/root/reference/pkg/firmament/resource_stats.proto:36-39,56-59), the reference's own
 // vectors carry absolute quantities (/root/reference/pkg/stats/stats_test.go:100-127: utilisation
-// 2000.0 of capacity 10000).  Values up to 1 are taken as fractions, larger ones as quantities.
-static i64 stats_quantity(double utilization, i64 capacity) {
+// 2000.0 of capacity 10000).  psn_svc_config::stats_utilization says which reading applies; the
+// default (0) takes values up to 1 as fractions and larger ones as quantities, which misreads an
+// absolute reading of at most one millicore or one Kb (a machine that is idle to the last unit is
+// priced as full): a caller that knows its feed sets 1 (always a fraction) or 2 (always a quantity).
+static i64 stats_quantity(double utilization, i64 capacity, int mode) {
     if (!(utilization > 0)) return 0;
-    const double q = utilization <= 1.0 ? utilization * (double)capacity : utilization;
+    const bool fraction = mode == 1 || (mode != 2 && utilization <= 1.0);
+    const double q = fraction ? utilization * (double)capacity : utilization;
     const double capped = std::min(q, (double)capacity);
     return (i64)(capped + 0.5);
 }
@@ -734,9 +740,9 @@ int psn_svc_add_node_stats_raw(psn_svc *s, const char *uuid, int32_t n_cpus, con
     i64 cpu = 0;
     for (int32_t i = 0; i < n_cpus; ++i) {  // one entry per CPU, or one for the whole node as the reference sends it (stats.go:60-66)
         if (cpu_capacity[i] < 0) return s->fail(PSN_EINVAL, "bad machine statistics");
-        cpu += stats_quantity(cpu_utilization[i], cpu_capacity[i]);
+        cpu += stats_quantity(cpu_utilization[i], cpu_capacity[i], s->cfg.stats_utilization);
     }
-    const i64 mem = stats_quantity(mem_utilization, mem_capacity);
+    const i64 mem = stats_quantity(mem_utilization, mem_capacity, s->cfg.stats_utilization);
     if (mc.meas_cpu != cpu || mc.meas_mem != mem) { mc.meas_cpu = cpu; mc.meas_mem = mem; s->any_measured = true; s->reprice = true; }
     return PSN_NODE_UPDATED_OK;
 }
@@ -949,6 +955,9 @@ int64_t psn_svc_schedule(psn_svc *s) {
         s->st.solve_ms = now_ms() - t0;
         if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("solve: ") + psn_last_error(s->ctx)); }
     }
+    // what the solver did, not what was asked for: a patch that outgrew the cost scale's head-room makes
+    // the solve after it a cold one although the network stayed resident
+    warm = res.warm_started != 0;
     s->st.last_round_warm = warm ? 1 : 0;
     if (warm) ++s->st.warm_rounds;
     s->st.total_cost = res.total_cost;

@@ -22,17 +22,19 @@ def write(path: str, n: int, row_off, head, cap, cost, supply, comment: str = "l
 
 
 def read(path: str):
-    """-> dict(n, m, tail, head, cap, cost, supply, base_cost) with 0-based ids."""
+    """-> dict(n, m, tail, head, cap, cost, supply, base_cost, low) with 0-based ids; cap is the
+    capacity above the lower bound `low`, which is already routed (supply, base_cost)."""
     lib = _lib.load_library()
     n, m = C.c_int32(), C.c_int64()
     _lib.check(lib.psn_dimacs_size(path.encode(), C.byref(n), C.byref(m)))
     n, m = n.value, m.value
-    tail, head, cap, cost = (np.empty(m, np.int32) for _ in range(4))
+    tail, head, cap, cost, low = (np.empty(m, np.int32) for _ in range(5))
     supply = np.empty(n, np.int64)
     base = C.c_int64()
-    _lib.check(lib.psn_dimacs_read(path.encode(), n, m, tail.ctypes.data, head.ctypes.data, cap.ctypes.data, cost.ctypes.data,
-                                   supply.ctypes.data, C.byref(base)))
-    return {"n": n, "m": m, "tail": tail, "head": head, "cap": cap, "cost": cost, "supply": supply, "base_cost": base.value}
+    _lib.check(lib.psn_dimacs_read_lower(path.encode(), n, m, tail.ctypes.data, head.ctypes.data, cap.ctypes.data, cost.ctypes.data,
+                                         supply.ctypes.data, C.byref(base), low.ctypes.data))
+    return {"n": n, "m": m, "tail": tail, "head": head, "cap": cap, "cost": cost, "supply": supply, "base_cost": base.value,
+            "low": low}
 
 
 def write_changes(path: str, arc_changes=(), supply_changes=(), comment: str = "libpsn change records"):
@@ -50,15 +52,18 @@ def write_changes(path: str, arc_changes=(), supply_changes=(), comment: str = "
 
 def read_changes(path: str, problem: dict):
     """Change records resolved against a problem read by read(): -> dict(arc, cap, cost, vertex,
-    supply) where arc[i] indexes the problem's arc list."""
+    supply) where arc[i] indexes the problem's arc list.  A record for an arc that had a lower bound
+    in the problem file is refused (PsnError, PSN_EINVAL)."""
     lib = _lib.load_library()
     na, ns = C.c_int64(), C.c_int64()
     _lib.check(lib.psn_dimacs_changes_size(path.encode(), C.byref(na), C.byref(ns)))
     arc = np.empty(na.value, np.int64); cap = np.empty(na.value, np.int32); cost = np.empty(na.value, np.int32)
     vertex = np.empty(ns.value, np.int32); supply = np.empty(ns.value, np.int64)
     tail = np.ascontiguousarray(problem["tail"], np.int32); head = np.ascontiguousarray(problem["head"], np.int32)
-    _lib.check(lib.psn_dimacs_read_changes(path.encode(), int(problem["n"]), int(problem["m"]), tail.ctypes.data, head.ctypes.data,
-                                           arc.ctypes.data, cap.ctypes.data, cost.ctypes.data, vertex.ctypes.data, supply.ctypes.data))
+    low = np.ascontiguousarray(problem.get("low", np.zeros(int(problem["m"]), np.int32)), np.int32)
+    _lib.check(lib.psn_dimacs_read_changes_lower(path.encode(), int(problem["n"]), int(problem["m"]), tail.ctypes.data, head.ctypes.data,
+                                                 low.ctypes.data, arc.ctypes.data, cap.ctypes.data, cost.ctypes.data, vertex.ctypes.data,
+                                                 supply.ctypes.data))
     return {"arc": arc, "cap": cap, "cost": cost, "vertex": vertex, "supply": supply}
 
 

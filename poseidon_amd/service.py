@@ -22,7 +22,7 @@ class SvcConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_machines", C.c_int32), ("max_tasks", C.c_int32),
                 ("max_jobs", C.c_int32), ("max_classes", C.c_int32), ("k_slots", C.c_int32),
                 ("slots_per_machine", C.c_int32), ("unsched_cost", C.c_int32), ("emit_noop", C.c_int32),
-                ("reschedule_running", C.c_int32), ("solver", _lib.Config)]
+                ("reschedule_running", C.c_int32), ("stats_utilization", C.c_int32), ("solver", _lib.Config)]
 
 
 class SvcStats(C.Structure):
@@ -97,12 +97,12 @@ class SchedulerService:
 
     def __init__(self, device: int = 0, max_machines: int = 0, max_tasks: int = 0, max_jobs: int = 0,
                  emit_noop: bool = False, slots_per_machine: int = 0, unsched_cost: int = 0,
-                 reschedule_running: bool = False):
+                 reschedule_running: bool = False, stats_utilization: int = 0):
         self._lib = _lib.load_library()
         _bind(self._lib)
         cfg = SvcConfig(device=device, max_machines=max_machines, max_tasks=max_tasks, max_jobs=max_jobs,
                         emit_noop=int(emit_noop), slots_per_machine=slots_per_machine, unsched_cost=unsched_cost,
-                        reschedule_running=int(reschedule_running))
+                        reschedule_running=int(reschedule_running), stats_utilization=int(stats_utilization))
         self._svc = C.c_void_p(None)
         rc = self._lib.psn_svc_create(C.byref(cfg), C.byref(self._svc))
         if rc != _lib.PSN_OK:
@@ -198,7 +198,10 @@ class SchedulerService:
         return self._lib.psn_svc_check(self._svc) == 1  # SERVING
 
     # ---- the scheduling round
-    def Schedule(self) -> list[SchedulingDelta]:
+    def schedule_arrays(self):
+        """One scheduling round with the reply as arrays: (task_uid uint64[d], type int32[d],
+        resource_uuid S36[d]) - what a caller that forwards the deltas (or counts them) wants; no
+        Python object per delta, so a first round over 100 000 tasks costs what the round costs."""
         cnt = self._lib.psn_svc_schedule(self._svc)
         if cnt < 0:
             raise _lib.PsnError(int(cnt), self._lib.psn_svc_last_error(self._svc).decode())
@@ -207,9 +210,11 @@ class SchedulerService:
         res = np.zeros((cnt, 37), np.uint8)
         if cnt:
             _lib.check(self._lib.psn_svc_get_deltas(self._svc, 0, cnt, uid.ctypes.data, typ.ctypes.data, res.ctypes.data))
-        raw = res.tobytes()
-        return [SchedulingDelta(int(uid[i]), raw[i * 37:(i + 1) * 37].split(b"\0", 1)[0].decode(), ChangeType(int(typ[i])))
-                for i in range(cnt)]
+        return uid, typ, np.ascontiguousarray(res[:, :36]).view("S36").reshape(cnt)
+
+    def Schedule(self) -> list[SchedulingDelta]:
+        uid, typ, res = self.schedule_arrays()
+        return [SchedulingDelta(int(u), r.decode(), ChangeType(int(t))) for u, t, r in zip(uid.tolist(), typ.tolist(), res.tolist())]
 
     def stats(self) -> SvcStats:
         st = SvcStats()

@@ -29,6 +29,8 @@ class SolveResult:
     solve_ms: float
     gu_arc_skips: int = 0
     arc_skips: int = 0
+    warm_started: int = 0
+    mirrored_replays: int = 0
 
     @property
     def algorithmic_bytes(self) -> int:

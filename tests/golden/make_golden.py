@@ -11,7 +11,13 @@ mathematics, not against the reference: parity with the reference stays unpinned
 
 Run from the repo root:  python tests/golden/make_golden.py
 then, optionally (tens of minutes):  python tests/golden/make_golden.py --nx-c1-only
-which adds the networkx cost of config 1 / seed 1 to the existing file.
+which adds the networkx cost of config 1 / seed 1 to the existing file;
+  python tests/golden/make_golden.py --ssp-c2
+adds the successive-shortest-paths optimum of the config 2 networks (about half an hour each,
+single thread), so that the full-size golden cost rests on two C oracles that agree;
+  python tests/golden/make_golden.py --c4
+writes psn_c4_costs.json: the cost-scaling optimum (certificate checked) and the CSR checksum of
+the 256 config 1 networks of the what-if batch (network b uses seed b + 1).
 """
 import json
 import os
@@ -54,10 +60,54 @@ def patch_nx_c1(path):
     print("networkx config 1 seed 1:", cost)
 
 
+def _c4_member(seed):
+    g = synth.build_graph(synth.make_cluster(1, seed))
+    rc, tc, cap, price, _ = capi.cost_scaling(g)
+    assert rc == 0
+    crc, ctc, _ = capi.check(g, cap, price)
+    assert crc == 0 and ctc == tc
+    return seed, tc, "%016x" % capi.csr_checksum(g)
+
+
+def make_c4(path, graphs=256, procs=4):
+    import multiprocessing as mp
+    with mp.Pool(procs) as pool:
+        rows = pool.map(_c4_member, range(1, graphs + 1), chunksize=4)
+    out = {"family": "psn-synth-v1", "config": 1, "graphs": graphs, "seed_of_graph_b": "b + 1",
+           "oracle": "oracle/psn_oracle.c cost scaling, optimality certificate checked",
+           "optimal_cost": [r[1] for r in rows], "csr_fnv1a64": [r[2] for r in rows]}
+    assert [r[0] for r in rows] == list(range(1, graphs + 1))
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote", path, "checksum of costs", sum(out["optimal_cost"]))
+
+
+def patch_ssp_c2(path):
+    with open(path) as f:
+        out = json.load(f)
+    for e in out["entries"]:
+        if e["config"] != 2 or "ssp" in e:
+            continue
+        g = synth.build_graph(synth.make_cluster(2, e["seed"]))
+        t = time.time()
+        rc, tcs, caps, _ = capi.ssp(g)
+        assert rc == 0 and capi.check(g, caps)[0] == 0
+        assert tcs == e["optimal_cost"], (tcs, e["optimal_cost"])
+        e["ssp"] = tcs
+        e["ssp_s"] = round(time.time() - t, 1)
+        print("config 2 seed", e["seed"], "ssp", tcs, e["ssp_s"], "s", flush=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+
+
 def main():
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "psn_synth_v1.json")
     if "--nx-c1-only" in sys.argv:
         return patch_nx_c1(path)
+    if "--ssp-c2" in sys.argv:
+        return patch_ssp_c2(path)
+    if "--c4" in sys.argv:
+        return make_c4(os.path.join(os.path.dirname(path), "psn_c4_costs.json"))
     nx_c1 = False
     out = {"family": "psn-synth-v1", "entries": []}
     for cfg in (0, 1, 2):

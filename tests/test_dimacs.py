@@ -123,3 +123,42 @@ def test_change_records_resolve_against_the_problem(tmp_path):
         bad.write_text(text)
         with pytest.raises(_lib.PsnError):
             dimacs.read_changes(str(bad), d)
+
+
+def test_change_record_on_an_arc_with_a_folded_lower_bound_is_refused(tmp_path):
+    """The reader stores capacity hi - lo for an arc with a lower bound and moves lo into the supplies and
+    the base cost; an `x` record carries only a new upper bound and cost, so applying it to such an arc
+    would give the wrong residual capacity and leave the base cost stale: refused.  The same record on an
+    arc without a lower bound goes through."""
+    p = tmp_path / "low.min"
+    p.write_text("p min 3 3\nn 1 3\nn 3 -3\na 1 2 1 3 5\na 2 3 0 3 1\na 1 3 0 2 4\n")
+    d = dimacs.read(str(p))
+    assert d["low"].tolist() == [1, 0, 0]
+    ok = tmp_path / "ok.chg"
+    ok.write_text("x 2 3 0 2 1\n")
+    assert dimacs.read_changes(str(ok), d)["arc"].tolist() == [1]
+    bad = tmp_path / "bad.chg"
+    bad.write_text("x 1 2 0 2 5\n")
+    with pytest.raises(_lib.PsnError) as ei:
+        dimacs.read_changes(str(bad), d)
+    assert ei.value.code == _lib.PSN_EINVAL
+
+
+def test_over_long_lines_are_refused_not_split(tmp_path):
+    """A line longer than the readers' buffer would be cut and its tail parsed as a record of its own
+    ("a 1 2 0 1 1" at the end of a long comment line); such files are refused instead."""
+    pad = "c " + "x" * 600 + "\n"
+    p = tmp_path / "long.min"
+    p.write_text("p min 2 1\n" + pad + "n 1 1\nn 2 -1\na 1 2 0 1 1\n")
+    with pytest.raises(_lib.PsnError):
+        dimacs.read(str(p))
+    # exactly at the limit (510 characters + newline) is fine
+    fit = "c " + "y" * 508 + "\n"
+    assert len(fit) == 511
+    p.write_text("p min 2 1\n" + fit + "n 1 1\nn 2 -1\na 1 2 0 1 1\n")
+    d = dimacs.read(str(p))
+    assert d["m"] == 1
+    ch = tmp_path / "long.chg"
+    ch.write_text(pad + "x 1 2 0 1 1\n")
+    with pytest.raises(_lib.PsnError):
+        dimacs.read_changes(str(ch), d)

@@ -205,3 +205,23 @@ def test_resource_stats_fields_map_to_machine_usage():
         assert s.AddNodeStats(machine_uuid(0), 700, 7000) == NR.NODE_UPDATED_OK
         ex = s.export_network()
         assert (int(ex["used_cpu"][0]), int(ex["used_mem"][0])) == (700, 7000)
+
+
+def test_resource_stats_reading_at_the_boundary_is_a_configured_choice():
+    """A utilisation of exactly 1.0 is the whole capacity as a fraction and one millicore / one Kb as
+    a quantity.  By default values up to 1.0 are fractions (what the message text says); a service
+    configured for absolute figures (what the reference's own vectors carry) reads 1.0 and 0.5 as
+    one unit and half a unit (rounded), and one configured for fractions reads 2000.0 as over the
+    capacity and cuts it to the capacity."""
+    want = {0: (10000, 1000000, 5000, 2000), 1: (10000, 1000000, 5000, 10000), 2: (1, 1, 1, 2000)}
+    for mode, (cpu1, mem1, cpu_half, cpu_2000) in want.items():
+        with pa.SchedulerService(device=-1, stats_utilization=mode) as s:
+            for m in range(3):
+                assert s.NodeAdded(machine_uuid(m), 10000, 1000000) == NR.NODE_ADDED_OK
+            assert s.AddNodeStatsRaw(machine_uuid(0), [(10000, 1.0)], 1000000, 1.0) == NR.NODE_UPDATED_OK
+            assert s.AddNodeStatsRaw(machine_uuid(1), [(10000, 0.5)], 1000000, 0.0) == NR.NODE_UPDATED_OK
+            assert s.AddNodeStatsRaw(machine_uuid(2), [(10000, 2000.0)], 1000000, 0.0) == NR.NODE_UPDATED_OK
+            assert s.TaskSubmitted(1, "job-0", 100, 1000) == TR.TASK_SUBMITTED_OK
+            ex = s.export_network()
+            assert (int(ex["used_cpu"][0]), int(ex["used_mem"][0])) == (cpu1, mem1), mode
+            assert int(ex["used_cpu"][1]) == cpu_half and int(ex["used_cpu"][2]) == cpu_2000, mode
