@@ -44,7 +44,7 @@ typedef struct psn_ctx psn_ctx;
 
 typedef struct psn_config {
     int32_t device;          /* HIP device ordinal */
-    int32_t alpha_log2;      /* epsilon divisor per refine, alpha = 2^alpha_log2; 0 -> default alpha_log2 = 3, i.e. alpha = 8 */
+    int32_t alpha_log2;      /* epsilon divisor per refine, alpha = 2^alpha_log2; 0 -> default alpha_log2 = 4, i.e. alpha = 16 */
     int32_t rounds_per_batch;/* push/relabel rounds between global price updates (0 -> default) */
     int32_t flags;           /* PSN_CFG_* */
 } psn_config;

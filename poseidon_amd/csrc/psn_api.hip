@@ -214,6 +214,7 @@ int enqueue_replay(psn_ctx *c, hipStream_t s) {
         ++launches;                                                       \
     } while (0)
     hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, g, c->rounds); ++launches;
+    L(PSN_KT_OTHER, k_flip, gv1, g, 0);
     L(PSN_KT_SATURATE, k_saturate, gs, g);
     L(PSN_KT_OTHER, k_gu_init, gv, g);
     for (int k = 0; k < kGuIters; ++k) L(PSN_KT_GU_EXPAND, k_gu_expand, gs, g, k);
@@ -1189,6 +1190,12 @@ static Ctrl solve_init(psn_ctx *c, bool warm, const i64 *h_scalar) {
     init.eps_shift = shift0;
     init.eps = (i64)1 << shift0;
     init.need_sat = 1;
+    // replays on the reversed network (see Orient in the kernels and k_begin): from an epsilon of 64 cost units down
+    init.mirror_max_shift = ceil_log2(g.scale) + 6;
+    init.mirror_ratio = 3;  // in quarters: as soon as the deficits sit at no more than 4/3 as many vertices as this side has work items
+    if (const char *ev = std::getenv("PSN_MIRROR_DELTA")) init.mirror_max_shift = ceil_log2(g.scale) + atoi(ev);  // development: relative to one cost unit
+    if (const char *ev = std::getenv("PSN_MIRROR_SHIFT")) init.mirror_max_shift = atoi(ev);  // development: -1 never, 62 in every phase
+    if (const char *ev = std::getenv("PSN_MIRROR_RATIO")) init.mirror_ratio = std::max(0, atoi(ev));
     // supplies that do not sum to zero cannot be routed: the solve ends at its first control step
     if (h_scalar[kSupplySumSlot] != 0) init.error = PSN_EINFEASIBLE_DEV;
     return init;
@@ -1202,6 +1209,7 @@ static int solve_start(psn_ctx *c, hipStream_t s, bool warm, const i64 *h_scalar
 // the context's pinned control block; all valid after the stream has drained).
 static int solve_finish(psn_ctx *c, hipStream_t s, i64 *h_cost, unsigned long long *h_tally) {
     const DevGraph &g = c->g;
+    hipLaunchKernelGGL(k_flip, dim3(std::max(1, std::min(kGrid, (g.n + kBlock - 1) / kBlock))), dim3(kBlock), 0, s, g, 1);  // prices and excesses the way the network is stored
     hipLaunchKernelGGL(k_total_cost, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar);
     hipLaunchKernelGGL(k_tally_sum, dim3(1), dim3(64 * kTallyN), 0, s, g, c->d_tally_out, c->tally_slots);
     HIPCHK(c, hipMemcpyAsync(h_cost, c->d_scalar, sizeof(i64), hipMemcpyDeviceToHost, s));
@@ -1229,6 +1237,7 @@ static void solve_report(psn_ctx *c, psn_result *out, int status, i64 cost, cons
     out->solve_ms = ms;
     out->gu_arc_skips = h_tally[kTallyGuSkips];
     out->arc_skips = h_tally[kTallySkips];
+    out->mirrored_replays = (int32_t)c->h_ctrl->tally_mirror;
     c->solved = status == PSN_OK;
 }
 
@@ -1295,7 +1304,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
                 const unsigned *lc = h.list_cnt[c->rounds & 1];
                 if (h.rounds_on && std::getenv("PSN_DEBUG_PHASES")) {
                     const double at = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
-                    fprintf(stderr, "     shift %d: items %u units %u  at %.2f ms (host clock)\n", h.eps_shift, lc[0] + lc[1], lc[2], at);
+                    fprintf(stderr, "     shift %d%s: items %u units %u deficit vertices %u  at %.2f ms (host clock)\n", h.eps_shift, h.mirror ? " mirrored" : "", lc[0] + lc[1], lc[2], lc[3], at);
                 }
             }
             if (h.eps_shift != last_shift && last_shift >= 0) { phase_log += " " + std::to_string(last_shift) + ":" + std::to_string(phase_replays + 1); phase_replays = 0; }
@@ -1354,6 +1363,7 @@ int group_enqueue_replay(const std::vector<psn_ctx *> &m, const DevGraph *d_grap
     const int rounds = m[0]->rounds;
 #define LG(kern, grid, ...) do { hipLaunchKernelGGL(kern, dim3(grid, G), dim3(kBlock), 0, s, d_graphs, ##__VA_ARGS__); ++launches; } while (0)
     hipLaunchKernelGGL(k_begin_group, dim3(1, G), dim3(1), 0, s, d_graphs, rounds); ++launches;
+    LG(k_flip_group, gv1, 0);
     LG(k_saturate_group, gs);
     LG(k_gu_init_group, gv);
     for (int k = 0; k < kGuIters; ++k) LG(k_gu_expand_group, gs, k);
@@ -1531,6 +1541,7 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
         if (h_status[2 * i + 1]) status[i] = h_status[2 * i + 1] == PSN_EINFEASIBLE_DEV ? PSN_EINFEASIBLE : PSN_EDEVICE;
     // read-out of all members: objective (scalar word 0 of each), work counters, control blocks
     GCHK(hipMemsetAsync(gc->d_scalars, 0, G * kScalarSlots * sizeof(i64), s));
+    hipLaunchKernelGGL(k_flip_group, ga, dim3(kBlock), 0, s, gc->d_graphs, 1);
     hipLaunchKernelGGL(k_total_cost_group, ga, dim3(kBlock), 0, s, gc->d_graphs, gc->d_aux);
     hipLaunchKernelGGL(k_tally_sum_group, dim3(1, (unsigned)G), dim3(64 * kTallyN), 0, s, gc->d_graphs, gc->d_aux, kSweepWaves);
     GCHK(hipMemcpyAsync(gc->h_scalars, gc->d_scalars, G * kScalarSlots * sizeof(i64), hipMemcpyDeviceToHost, s));

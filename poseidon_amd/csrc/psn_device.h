@@ -28,7 +28,7 @@ constexpr int kClsSeg = 1;       // counter slot of the (vertex, segment) item l
 constexpr int kHubPull = -2;     // hub_of[] value of a pull vertex (see DevGraph::pull_list); -1: an ordinary vertex
 constexpr int kMaxHubs = 128;    // highest-degree vertices whose atomics are pre-combined in LDS per workgroup
 constexpr double kTailFactor = 0.213, kTailPower = 0.65;  // Ctrl::tail_units = kTailFactor * (total supply)^kTailPower
-constexpr int kDefaultAlphaLog2 = 3;  // epsilon / 8 per phase
+constexpr int kDefaultAlphaLog2 = 4;  // epsilon / 16 per phase
 constexpr int kGuIters = 12;     // frontier expansions per replay (multiple of 3)
 constexpr int PSN_EINFEASIBLE_DEV = -4;
 
@@ -47,10 +47,16 @@ struct Ctrl {
     int sat_on, gu_on, gu_init_on, rounds_on;
     int done, error;
     unsigned epoch, gu_stamp_base;
-    unsigned list_cnt[2][4];  // per list parity: lane items, wave items, units of excess at the listed vertices, -
+    unsigned list_cnt[2][4];  // per list parity: lane items, wave items, units of excess at the listed vertices, vertices that hold a deficit
     unsigned fr_cnt[3][4];
     int gu_phase[2];  // global update, read by expansion k at [k & 1], written at [(k + 1) & 1]: 0 expanding, 1 the pull sweep just ran, 2 converged
     unsigned long long tally_refines, tally_gus;
+    // Orientation (see Orient in the kernels): mirror = 1 while the sweeps work on the reversed
+    // network; k_begin decides per replay, k_flip (flip_on) negates prices and excesses in place.
+    int mirror, flip_on;
+    int mirror_max_shift;   // replays may run mirrored in phases with eps_shift <= this (-1: never)
+    int mirror_ratio;       // ... changing sides when (vertices holding a deficit) * mirror_ratio / 4 <= work items of the current side (0: never)
+    unsigned long long tally_mirror;  // replays run mirrored
 };
 
 // Plain-pointer view of one flow network in HBM (struct of arrays).
@@ -117,6 +123,7 @@ __global__ void k_gu_init(DevGraph g);
 __global__ void k_gu_expand(DevGraph g, int k);
 __global__ void k_gu_apply(DevGraph g, int n_iters);
 __global__ void k_begin(DevGraph g, int n_rounds);
+__global__ void k_flip(DevGraph g, int unflip);
 __global__ void k_push_group(const DevGraph *gs, int k);
 __global__ void k_relabel_compact_group(const DevGraph *gs, int k, int do_relabel);
 __global__ void k_saturate_group(const DevGraph *gs);
@@ -124,6 +131,7 @@ __global__ void k_gu_init_group(const DevGraph *gs);
 __global__ void k_gu_expand_group(const DevGraph *gs, int k);
 __global__ void k_gu_apply_group(const DevGraph *gs, int n_iters);
 __global__ void k_begin_group(const DevGraph *gs, int n_rounds);
+__global__ void k_flip_group(const DevGraph *gs, int unflip);
 __global__ void k_group_status(const DevGraph *gs, int count, int n_rounds, int *status);
 __global__ void k_reset(DevGraph g, const i64 *supply, int keep_flow);
 __global__ void k_mirror(DevGraph g, const i64 *supply, int recompute_excess);

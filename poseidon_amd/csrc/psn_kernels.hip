@@ -30,7 +30,10 @@ static constexpr i64 kNegInf = INT64_MIN;
 // under shorter lengths still satisfy d(u) <= d(v) + length(u,v) for the true lengths, which
 // is all the price update needs; with at most 2^28 vertices distances stay below 2^46.
 static constexpr i64 kDistInf = (i64)1 << 46;
-static constexpr i64 kLenMax = (i64)1 << 18;
+#ifndef PSN_LENMAX_LOG2
+#define PSN_LENMAX_LOG2 18
+#endif
+static constexpr i64 kLenMax = (i64)1 << PSN_LENMAX_LOG2;
 __device__ __forceinline__ i64 dist_pack(i64 d, unsigned stamp16) { return (d << 16) | (i64)stamp16; }
 __device__ __forceinline__ i64 dist_of(i64 packed) { return packed >> 16; }
 
@@ -330,9 +333,28 @@ __device__ __forceinline__ void seg_note(const DevGraph &g, int hub, int r, i64 
     amax64(&g.seg_add[par][s], key);
 }
 
+// ------------------------------------------------------------------- orientation
+// The sweeps can work on the network as it is or on its mirror image: every arc reversed, supplies
+// and prices negated.  In the residual CSR the mirror needs no second copy: the reverse of arc a
+// sits at rev[a] in the row of a's head, so row u of the mirror is row u of the original with
+// cap and rcap (= cap[rev]) exchanged and the costs negated; price[] and excess[] hold the
+// negated values while the mirror is worked on (k_flip negates them in place), and negating the
+// cost scale negates every cost * scale product.  Pushing excess in the mirror is pulling flow
+// towards the deficits of the original: a vertex that holds a large deficit (a task class whose
+// arcs a saturation filled) spreads it over its neighbours in a round or two, where the excesses
+// that look for it from the other side get through one unit per global update.
+struct Orient { int *cap, *rcap; i64 S; };
+__device__ __forceinline__ Orient orient_of(const DevGraph &g, int mirror) {
+    Orient o;
+    o.cap = mirror ? g.rcap : g.cap;
+    o.rcap = mirror ? g.cap : g.rcap;
+    o.S = mirror ? -g.scale : g.scale;
+    return o;
+}
+
 // --------------------------------------------------------------------------- pushes
 // Low-degree vertex: one lane, all loads of its (at most kLowMax) arcs issued together.
-__device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, int2 it, i64 S, int par, Tally &t) {
+__device__ __forceinline__ void push_low(const DevGraph &g, const Orient &o, const HubAcc &hb, int2 it, i64 S, int par, Tally &t) {
     const int u = it.x & 0x0FFFFFFF;
     const unsigned deg = (unsigned)it.x >> 28, r0 = (unsigned)it.y;
     const i64 pu = g.price[u];
@@ -341,7 +363,7 @@ __device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, in
 #pragma unroll
     for (unsigned j = 0; j < kLowMax; ++j) {
         const bool ok = j < deg;
-        cp[j] = ok ? g.cap[r0 + j] : 0; hd[j] = ok ? g.head[r0 + j] : 0; cs[j] = ok ? g.cost[r0 + j] : 0;
+        cp[j] = ok ? o.cap[r0 + j] : 0; hd[j] = ok ? g.head[r0 + j] : 0; cs[j] = ok ? g.cost[r0 + j] : 0;
     }
     i64 key[kLowMax];
 #pragma unroll
@@ -355,8 +377,8 @@ __device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, in
             const i64 d = e < cp[j] ? e : cp[j];
             const unsigned a = r0 + j;
             const int r = g.rev[a];
-            const int na = cp[j] - (int)d, nr = g.rcap[a] + (int)d;
-            g.cap[a] = na; g.cap[r] = nr; g.rcap[a] = nr; g.rcap[r] = na;
+            const int na = cp[j] - (int)d, nr = o.rcap[a] + (int)d;
+            o.cap[a] = na; o.cap[r] = nr; o.rcap[a] = nr; o.rcap[r] = na;
             const int h = g.hub_of[hd[j]];
             const i64 kr = pu + (i64)cs[j] * S;
             if (h >= 0) { lds_add(&hb.add[h], d); lds_max(&hb.ext[h], kr); seg_note(g, h, r, kr, par); }
@@ -376,7 +398,7 @@ __device__ __forceinline__ void push_low(const DevGraph &g, const HubAcc &hb, in
 // one arc's worth of instructions per lane instead of nine; the prefix order of the grants is
 // the order of the records, which is the (rotated) lane order of the dense step.
 struct StepOut { i64 here; bool stop; };
-__device__ __forceinline__ StepOut push_step_sparse(const DevGraph &g, const HubAcc &hb, int2 *slive, const int (&cp)[9], unsigned lm,
+__device__ __forceinline__ StepOut push_step_sparse(const DevGraph &g, const Orient &o, const HubAcc &hb, int2 *slive, const int (&cp)[9], unsigned lm,
                                                     unsigned off, unsigned total_live, unsigned a0, unsigned at, unsigned safe, i64 pu,
                                                     i64 S, i64 &e, int par, Tally &t) {
     const int lane = lane_id();
@@ -390,7 +412,7 @@ __device__ __forceinline__ StepOut push_step_sparse(const DevGraph &g, const Hub
     const int2 rec = slive[has ? lane : 0];
     const unsigned a = has ? (unsigned)rec.x : safe;
     const int c = has ? rec.y : 0;
-    const int hd = g.head[a], cs = g.cost[a], rv = g.rev[a], cr = g.rcap[a];  // one round trip for all four
+    const int hd = g.head[a], cs = g.cost[a], rv = g.rev[a], cr = o.rcap[a];  // one round trip for all four
     const i64 ph = ld_sel(has, &g.price[hd], g.spare);
     const int hub = ld_sel(has, &g.hub_of[hd], g.spare);
     const i64 key = ph - (i64)cs * S;
@@ -407,7 +429,7 @@ __device__ __forceinline__ StepOut push_step_sparse(const DevGraph &g, const Hub
         if (adm && mine > 0) {
             d = (int)(mine < (i64)c ? mine : (i64)c);
             const int na = c - d, nr = cr + d;
-            g.cap[a] = na; g.cap[rv] = nr; g.rcap[a] = nr; g.rcap[rv] = na;
+            o.cap[a] = na; o.cap[rv] = nr; o.rcap[a] = nr; o.rcap[rv] = na;
             const i64 kr = pu + (i64)cs * S;  // key of the new residual arc (v,u)
             if (hub >= 0) { lds_add(&hb.add[hub], (i64)d); lds_max(&hb.ext[hub], kr); seg_note(g, hub, rv, kr, par); }
             else { aadd64(&g.excess[hd], (i64)d); amax64(&g.cand[hd], kr); }
@@ -416,11 +438,11 @@ __device__ __forceinline__ StepOut push_step_sparse(const DevGraph &g, const Hub
         stop = granted < total || e == 0;  // out of excess
     }
     // the lane's share of the relabel candidate, as the dense step works it out from its nine arcs
-    StepOut o;
-    o.here = !has ? kNegInf : (adm ? (c - d > 0 ? key : kNegInf) : key);
-    o.stop = stop;
+    StepOut so;
+    so.here = !has ? kNegInf : (adm ? (c - d > 0 ? key : kNegInf) : key);
+    so.stop = stop;
     __builtin_amdgcn_wave_barrier();  // the record is read before the next step or item overwrites it
-    return o;
+    return so;
 }
 
 // One wave item.  A solo vertex keeps its excess in a register; a vertex split over
@@ -428,7 +450,7 @@ __device__ __forceinline__ StepOut push_step_sparse(const DevGraph &g, const Hub
 // what was not granted.  `rot` permutes which lane owns which arcs, so that the prefix
 // order (= who gets the excess first) changes from round to round.
 template <bool SOLO>
-__device__ __forceinline__ void push_item_t(const DevGraph &g, const HubAcc &hb, int2 *slive, int4 it, i64 S, unsigned rot, int par, Tally &t) {
+__device__ __forceinline__ void push_item_t(const DevGraph &g, const Orient &o, const HubAcc &hb, int2 *slive, int4 it, i64 S, unsigned rot, int par, Tally &t) {
     const int lane = lane_id();
     const int u = it.x;
     const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
@@ -442,7 +464,7 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const HubAcc &hb,
         // away, so nothing has to be known before the capacities of the first step are asked for.
         // They travel with the vertex words; heads and costs follow for the lanes that found a
         // residual arc (the rows of machines are mostly reverse arcs without flow).
-        load9(g.cap, r0 + plane * 8, min(r1, r0 + 512), r0 + 512 + plane, min(r1, r0 + kStep), cp);
+        load9(o.cap, r0 + plane * 8, min(r1, r0 + 512), r0 + 512 + plane, min(r1, r0 + kStep), cp);
     }
     if (seg1) {
         // no residual arc of the segment has a key above the bound: with bound <= price[u] none is
@@ -468,7 +490,7 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const HubAcc &hb,
     for (unsigned h = r0; h < r1; h += kStep) {
         const unsigned a0 = h + plane * 8, lim8 = min(r1, h + 512), at = h + 512 + plane, limt = min(r1, h + kStep);
         int hd[9], cs[9];
-        if (!SOLO || h != r0) load9(g.cap, a0, lim8, at, limt, cp);
+        if (!SOLO || h != r0) load9(o.cap, a0, lim8, at, limt, cp);
         t.c[kTallyScans] += count9(a0, lim8, at, limt);
         bool lane_live = true;
         if constexpr (SOLO) {
@@ -479,9 +501,9 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const HubAcc &hb,
             const unsigned nl = (unsigned)__popc(lm), incl_l = wave_incl_scan_u32(nl), total_live = (unsigned)__shfl((int)incl_l, 63);
             if (total_live <= 64u) {  // wave-uniform
                 t.c[kTallySkips] += count9(a0, lim8, at, limt) - nl;
-                const StepOut o = push_step_sparse(g, hb, slive, cp, lm, incl_l - nl, total_live, a0, at, h, pu, S, e, par, t);
-                best = o.here > best ? o.here : best;
-                if (o.stop) {
+                const StepOut so = push_step_sparse(g, o, hb, slive, cp, lm, incl_l - nl, total_live, a0, at, h, pu, S, e, par, t);
+                best = so.here > best ? so.here : best;
+                if (so.stop) {
                     if (h + kStep < r1) incomplete = true;
                     break;
                 }
@@ -547,7 +569,7 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const HubAcc &hb,
                         const int j = b0 + x < 9 ? b0 + x : 8;
                         const bool on = d[x] > 0;
                         const unsigned ax = on ? arc9(a0, at, j) : h;  // no control flow around the loads (see ld_sel)
-                        const int rvx = g.rev[ax], crx = g.rcap[ax], hbx = ld_sel(on, &g.hub_of[hd[j]], g.spare);
+                        const int rvx = g.rev[ax], crx = o.rcap[ax], hbx = ld_sel(on, &g.hub_of[hd[j]], g.spare);
                         rv[x] = on ? rvx : 0; hub[x] = on ? hbx : -1; cr[x] = on ? crx : 0;
                     }
 #pragma unroll
@@ -556,7 +578,7 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const HubAcc &hb,
                         if (d[x] > 0) {
                             const unsigned a = arc9(a0, at, j);
                             const int na = cp[j] - d[x], nr = cr[x] + d[x];
-                            g.cap[a] = na; g.cap[rv[x]] = nr; g.rcap[a] = nr; g.rcap[rv[x]] = na;
+                            o.cap[a] = na; o.cap[rv[x]] = nr; o.rcap[a] = nr; o.rcap[rv[x]] = na;
                             const i64 kr = pu + (i64)cs[j] * S;  // key of the new residual arc (v,u)
                             if (hub[x] >= 0) { lds_add(&hb.add[hub[x]], (i64)d[x]); lds_max(&hb.ext[hub[x]], kr); seg_note(g, hub[x], rv[x], kr, par); }
                             else { aadd64(&g.excess[hd[j]], (i64)d[x]); amax64(&g.cand[hd[j]], kr); }
@@ -592,9 +614,9 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const HubAcc &hb,
     }
 }
 
-__device__ __forceinline__ void push_item(const DevGraph &g, const HubAcc &hb, int2 *slive, int4 it, i64 S, unsigned rot, int par, Tally &t) {
-    if (it.w & 1) push_item_t<true>(g, hb, slive, it, S, rot, par, t);
-    else push_item_t<false>(g, hb, slive, it, S, rot, par, t);
+__device__ __forceinline__ void push_item(const DevGraph &g, const Orient &o, const HubAcc &hb, int2 *slive, int4 it, i64 S, unsigned rot, int par, Tally &t) {
+    if (it.w & 1) push_item_t<true>(g, o, hb, slive, it, S, rot, par, t);
+    else push_item_t<false>(g, o, hb, slive, it, S, rot, par, t);
 }
 
 __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
@@ -602,8 +624,10 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     const unsigned *cnt = ct->list_cnt[k & 1];
     const int on = ct->rounds_on;
     const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg], epoch = ct->epoch;
-    CTRL_TOGETHER4(on, nlow, nseg, epoch);
+    const int mirror = ct->mirror;
+    CTRL_TOGETHER5(on, nlow, nseg, epoch, mirror);
     if (!on) return;
+    const Orient o = orient_of(g, mirror);
     if (blockIdx.x == 0 && threadIdx.x < 4) ct->list_cnt[(k + 1) & 1][threadIdx.x] = 0;
     if (nlow + nseg == 0) return;
     if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -614,7 +638,7 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     __shared__ int2 s_live[kBlock / 64][64];  // per wave: the residual arcs (index, capacity) of a sparse step
     const HubAcc hb{s_add, s_max};
     hub_init(hb, kNegInf);
-    const i64 S = g.scale;
+    const i64 S = o.S;
     const unsigned salt = epoch * 64u + (unsigned)k;
     const int2 *lowl = g.list_low[k & 1];
     const int4 *segl = g.list_seg[k & 1];
@@ -626,9 +650,9 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     for (unsigned i = wave; i < nseg; i += nwaves) {
         const int4 it = it_next;
         if (i + nwaves < nseg) it_next = segl[i + nwaves];  // on its way while this item is worked on
-        push_item(g, hb, s_live[threadIdx.x >> 6], it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t);
+        push_item(g, o, hb, s_live[threadIdx.x >> 6], it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t);
     }
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, hb, lowl[i], S, k & 1, t);
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, o, hb, lowl[i], S, k & 1, t);
     hub_flush_push(g, hb, my_hub_vertex);
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyRounds]++;
     tally_flush<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds, kTallySkips>(g, t);
@@ -650,6 +674,7 @@ __device__ __forceinline__ HubTurn hub_fetch(const DevGraph &g, int hv) {
     return h;
 }
 constexpr int kCntUnits = 2;     // work-list counter slot: units of excess at the listed vertices (a vertex counts for at most 2^16 - 1)
+constexpr int kCntDeficits = 3;  // work-list counter slot: vertices that hold a deficit (hubs included)
 __device__ __forceinline__ unsigned excess_units(i64 e) { return e > 0 ? (unsigned)(e < 65535 ? e : 65535) : 0u; }
 // The thread that looks after a hub relabels it and resets its candidate.
 __device__ __forceinline__ void hub_decide(const DevGraph &g, HubTurn &h, bool do_relabel, i64 eps, unsigned rot, Tally &t, unsigned *cnt) {
@@ -751,11 +776,15 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
             if (seg1[i] == 0 && c[i] != nc) g.cand[v[i]] = nc;
         }
         {
-            unsigned units = 0;
+            unsigned units = 0, ndef = 0;
 #pragma unroll
-            for (int i = 0; i < kVpt; ++i) units += act[i] ? excess_units(e[i]) : 0u;
+            for (int i = 0; i < kVpt; ++i) { units += act[i] ? excess_units(e[i]) : 0u; ndef += e[i] < 0; }  // e is 0 outside the vertex range
             units = wave_sum_u32(units);
             if (lane_id() == 0 && units) __hip_atomic_fetch_add(&ct->list_cnt[dst][kCntUnits], units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(ndef != 0)) {
+                ndef = wave_sum_u32(ndef);
+                if (lane_id() == 0) __hip_atomic_fetch_add(&ct->list_cnt[dst][kCntDeficits], ndef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app, hubs_pending ? hub_total : 0u, &hub_base);
         if (hubs_pending) { if (hub_total) append_hubs(s_hub, n_my_hubs, hub_base, g.list_seg[dst]); hubs_pending = false; }
@@ -779,7 +808,8 @@ __device__ __forceinline__ void saturate_body(const DevGraph &g) {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n_hub_segs; i += gridDim.x * kBlock) {
         g.seg_scan[i] = kInf; g.seg_add[0][i] = kNegInf; g.seg_add[1][i] = kNegInf;
     }
-    const i64 eps = ct->eps, S = g.scale;
+    const Orient o = orient_of(g, ct->mirror);
+    const i64 eps = ct->eps, S = o.S;
     Tally t;
     __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
     const HubAcc hb{s_add, s_max};
@@ -789,12 +819,12 @@ __device__ __forceinline__ void saturate_body(const DevGraph &g) {
         const unsigned a0 = q * 4;
         int cp[4], tl[4], hd[4], cs[4];
         if (a0 + 3 < g.m2) {
-            const int4u x = *reinterpret_cast<const int4u *>(g.cap + a0);
+            const int4u x = *reinterpret_cast<const int4u *>(o.cap + a0);
             cp[0] = x.x; cp[1] = x.y; cp[2] = x.z; cp[3] = x.w;
             t.c[kTallySat] += 4;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { cp[j] = a0 + j < g.m2 ? g.cap[a0 + j] : 0; if (a0 + j < g.m2) t.c[kTallySat]++; }
+            for (int j = 0; j < 4; ++j) { cp[j] = a0 + j < g.m2 ? o.cap[a0 + j] : 0; if (a0 + j < g.m2) t.c[kTallySat]++; }
         }
         if ((cp[0] | cp[1] | cp[2] | cp[3]) == 0) continue;  // capacities are never negative
         if (a0 + 3 < g.m2) {
@@ -819,8 +849,8 @@ __device__ __forceinline__ void saturate_body(const DevGraph &g) {
             if (cp[j] > 0 && rc[j] < -eps) {
                 const unsigned a = a0 + j;
                 const int r = g.rev[a];
-                const int nr = g.cap[r] + cp[j];
-                g.cap[a] = 0; g.cap[r] = nr; g.rcap[a] = nr; g.rcap[r] = 0;
+                const int nr = o.cap[r] + cp[j];
+                o.cap[a] = 0; o.cap[r] = nr; o.rcap[a] = nr; o.rcap[r] = 0;
                 excess_add(g, hb, tl[j], -(i64)cp[j]);
                 excess_add(g, hb, hd[j], (i64)cp[j]);
             }
@@ -966,8 +996,11 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     const unsigned npull = *g.pull_cnt;
     const int sh = ct->eps_shift;
     const unsigned stamp_base = ct->gu_stamp_base, epoch = ct->epoch;
+    const int mirror = ct->mirror;
     CTRL_TOGETHER8(on, nlow, nseg, phase, npull, sh, stamp_base, epoch);
+    CTRL_TOGETHER4(mirror, on, nlow, nseg);
     if (!on) return;
+    const Orient o = orient_of(g, mirror);
     if (blockIdx.x == 0 && threadIdx.x < 4) ct->fr_cnt[clr][threadIdx.x] = 0;
     // What this launch does follows from words it does not write: the frontier it reads and the
     // phase the launch before it left.  A dry frontier is followed by one sweep over the pull
@@ -993,7 +1026,10 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     unsigned *dcnt = ct->fr_cnt[dst];
     int2 *dlow = g.fr_low[dst];
     int4 *dseg = g.fr_seg[dst];
-    const i64 S = g.scale;
+    const i64 S = o.S;
+    // under a negative scale (mirror) the cheapest, not the dearest, of a group of parallel arcs has the shortest length
+    const int sgn = S < 0 ? -1 : 1;
+    const i64 Sabs = S < 0 ? -S : S;
     const unsigned stamp = (stamp_base + (unsigned)k) % 65535u + 1u;  // 16 bits, never 0
     const unsigned rot = mix32(epoch, stamp);
     const int lane = lane_id();
@@ -1017,7 +1053,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
 #pragma unroll
             for (unsigned j = 0; j < kLowMax; ++j) {  // entries past the row's end are read (the arrays have spare entries) and dropped
                 const bool ok = j < deg;
-                const int rcj = g.rcap[r0 + j], cpj = g.cap[r0 + j], hdj = g.head[r0 + j], csj = g.cost[r0 + j];
+                const int rcj = o.rcap[r0 + j], cpj = o.cap[r0 + j], hdj = g.head[r0 + j], csj = g.cost[r0 + j];
                 rc4[j] = ok ? rcj : 0; cp4[j] = ok ? cpj : 0; hd[j] = ok ? hdj : 0; cs[j] = ok ? csj : 0;
             }
             t.c[kTallyGuScans] += deg;
@@ -1077,7 +1113,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
             const unsigned a = r0 + (unsigned)lane;
             const bool in = a < r1;
             const unsigned ac = in ? a : r0;
-            const int rc_raw = g.rcap[ac], hd_raw = g.head[ac], cs_raw = g.cost[ac];
+            const int rc_raw = o.rcap[ac], hd_raw = g.head[ac], cs_raw = g.cost[ac];
             const int rc = in ? rc_raw : 0;
             int hd1[1] = {in ? hd_raw : 0}, hub1[1] = {-1};
             const int cs1 = in ? cs_raw : 0;
@@ -1092,7 +1128,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
             continue;
         }
         int rc_next[9];
-        load9(g.rcap, r0 + lane * 8, min(r1, r0 + 512), r0 + 512 + lane, min(r1, r0 + kStep), rc_next, true, r0);
+        load9(o.rcap, r0 + lane * 8, min(r1, r0 + 512), r0 + 512 + lane, min(r1, r0 + kStep), rc_next, true, r0);
         for (unsigned h = r0; h < r1; h += kStep) {
             const unsigned a0 = h + lane * 8, lim8 = min(r1, h + 512), at = h + 512 + lane, limt = min(r1, h + kStep);
             int rc9[9];
@@ -1100,7 +1136,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
             for (int j = 0; j < 9; ++j) rc9[j] = rc_next[j];
             if (h + kStep < r1) {  // the capacities of the item's next step travel while this one is worked on
                 const unsigned hn = h + kStep;
-                load9(g.rcap, hn + lane * 8, min(r1, hn + 512), hn + 512 + lane, min(r1, hn + kStep), rc_next, true, hn);
+                load9(o.rcap, hn + lane * 8, min(r1, hn + 512), hn + 512 + lane, min(r1, hn + kStep), rc_next, true, hn);
             }
             const unsigned mine = count9(a0, lim8, at, limt);
             t.c[kTallyGuScans] += mine;
@@ -1132,9 +1168,9 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                     hd2[0] = g.head[need8 ? a0 : h];
                     hd2[1] = g.head[needt ? at : h];
                 }
-                int c0 = INT32_MIN;
+                int c0 = INT32_MIN;  // largest sgn * cost among the group's residual arcs
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (rc9[j] > 0 && cs[j] > c0) c0 = cs[j];  // rc9 is 0 past the end of the range
+                for (int j = 0; j < 8; ++j) if (rc9[j] > 0 && sgn * cs[j] > c0) c0 = sgn * cs[j];  // rc9 is 0 past the end of the range
                 const bool on0 = need8 && c0 != INT32_MIN, on1 = needt && rc9[8] > 0;
                 i64 nd2[2] = {kDistInf, kDistInf};
                 const i64 p0 = ld_sel(on0, &g.price[hd2[0]], g.spare), p1 = ld_sel(on1, &g.price[hd2[1]], g.spare);
@@ -1142,7 +1178,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
                 const int hb0 = ld_sel(on0, &g.hub_of[hd2[0]], g.spare), hb1 = ld_sel(on1, &g.hub_of[hd2[1]], g.spare);
                 hub2[0] = on0 ? hb0 : -1;
                 hub2[1] = on1 ? hb1 : -1;
-                if (on0) { const i64 l = arc_len(-(i64)c0 * S + p0 - pv, sh); if (dv + l < d0) nd2[0] = dv + l; }
+                if (on0) { const i64 l = arc_len(-(i64)c0 * Sabs + p0 - pv, sh); if (dv + l < d0) nd2[0] = dv + l; }
                 if (on1) { const i64 l = arc_len(-(i64)cs[8] * S + p1 - pv, sh); if (dv + l < d1) nd2[1] = dv + l; }
                 gu_commit_batch<2>(g, q, dcnt, dlow, dseg, s_hmin, hd2, hub2, nd2, stamp, rot, wmax, t);
                 continue;
@@ -1195,7 +1231,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
 #pragma unroll
         for (unsigned j = 0; j < kLowMax; ++j) {  // entries past the row's end are read (the arrays have spare entries) and dropped
             const bool ok = j < deg;
-            const int rcj = g.rcap[r0 + j], hdj = g.head[r0 + j], csj = g.cost[r0 + j];
+            const int rcj = o.rcap[r0 + j], hdj = g.head[r0 + j], csj = g.cost[r0 + j];
             rc4[j] = ok ? rcj : 0; hd[j] = ok ? hdj : 0; cs[j] = ok ? csj : 0;
         }
         t.c[kTallyGuScans] += deg;
@@ -1376,8 +1412,28 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
         }
     }
     ct->epoch++;
-    ct->sat_on = ct->gu_on = ct->gu_init_on = ct->rounds_on = 0;
+    ct->sat_on = ct->gu_on = ct->gu_init_on = ct->rounds_on = ct->flip_on = 0;
     if (ct->done || ct->error) return;
+    // Which way round this replay works.  A phase starts the way the network is stored; a replay
+    // that opens a new global update inside a phase, once epsilon is within mirror_max_shift,
+    // changes sides when the other side's open units sit at few vertices compared with the work
+    // this side has queued (both counted by the last relabel sweep: work items of this side - a
+    // split vertex counts once per segment -, vertices with a deficit).  Pushing from the side
+    // where the units are concentrated fans them out; from the other side many units look for
+    // the same few vertices and get through one per update.  Measured over three sizes of
+    // scheduling networks and several seeds each: 2 deficit vertices per work item, from 64
+    // cost units of epsilon down, is the best of the settings tried (about a sixth less time).
+    {
+        int want = ct->mirror;
+        if (ct->need_sat) {
+            want = 0;
+        } else if (ct->need_gu && !ct->gu_active && ct->eps_shift <= ct->mirror_max_shift && ct->mirror_ratio > 0) {
+            const unsigned *c = ct->list_cnt[n_rounds & 1];
+            const unsigned long long items = (unsigned long long)c[kClsLow] + c[kClsSeg], ndef = c[kCntDeficits];
+            if (ndef > 0 && ndef * (unsigned long long)ct->mirror_ratio <= items * 4ull) want = !ct->mirror;
+        }
+        if (want != ct->mirror) { ct->mirror = want; ct->flip_on = 1; }
+    }
     if (ct->need_sat) { ct->sat_on = 1; ct->need_sat = 0; ct->need_gu = 1; ct->tally_refines++; }
     if (ct->need_gu) {
         ct->gu_on = 1;
@@ -1391,6 +1447,22 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
         } else {
             ct->gu_stamp_base += kGuIters;  // sweep stamps stay unique within one update
         }
+    }
+    if (ct->mirror) ct->tally_mirror++;
+}
+
+// Negates prices and excesses in place when the orientation changes (or, with `unflip`, when a
+// finished solve was left mirrored), and forgets the hub segment bounds: they bound keys of the
+// other orientation.
+__device__ __forceinline__ void flip_body(const DevGraph &g, int unflip) {
+    const Ctrl *ct = g.ctrl;
+    if (unflip ? !ct->mirror : !ct->flip_on) return;
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < g.n; v += gridDim.x * kBlock) {
+        g.price[v] = -g.price[v];
+        g.excess[v] = -g.excess[v];
+    }
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n_hub_segs; i += gridDim.x * kBlock) {
+        g.seg_scan[i] = kInf; g.seg_add[0][i] = kNegInf; g.seg_add[1][i] = kNegInf;
     }
 }
 
@@ -1752,6 +1824,8 @@ __global__ __launch_bounds__(kBlock) void k_gu_init_group(const DevGraph *__rest
 __global__ __launch_bounds__(kBlock) void k_gu_apply(DevGraph g, int n_iters) { gu_apply_body(g, n_iters); }
 __global__ __launch_bounds__(kBlock) void k_gu_apply_group(const DevGraph *__restrict__ gs, int n_iters) { gu_apply_body(gs[blockIdx.y], n_iters); }
 __global__ void k_begin(DevGraph g, int n_rounds) { begin_body(g, n_rounds); }
+__global__ __launch_bounds__(kBlock) void k_flip(DevGraph g, int unflip) { flip_body(g, unflip); }
+__global__ __launch_bounds__(kBlock) void k_flip_group(const DevGraph *__restrict__ gs, int unflip) { flip_body(gs[blockIdx.y], unflip); }
 __global__ void k_begin_group(const DevGraph *__restrict__ gs, int n_rounds) { begin_body(gs[blockIdx.y], n_rounds); }
 // done / error of every network of a group, side by side for one read-back per replay
 __global__ void k_group_status(const DevGraph *gs, int count, int n_rounds, int *status) {
