@@ -510,3 +510,40 @@ def test_leaf_vertices_that_fetch_their_own_distance(solver):
             continue
         r = solve_and_certify(solver, g)
         assert tc == r.total_cost, (trial, tc, r.total_cost)
+
+
+@pytest.mark.parametrize("ratio", ["1", "3", "12"])
+def test_replays_on_the_reversed_network_end_at_the_same_optimum(solver, monkeypatch, ratio):
+    """Replays may work on the mirror image of the network (arcs reversed, supplies and prices
+    negated, deficits pushed towards the excesses).  Forced on in every phase and with an eager, the
+    default and a reluctant threshold: random graphs (negative costs, large capacities, hubs) and
+    synthetic clusters reach the oracle's optimum with a certificate, the prices come back the way the
+    network is stored, and a warm re-solve from the state a mirrored solve left finds nothing to do."""
+    monkeypatch.setenv("PSN_MIRROR_DELTA", "40")
+    monkeypatch.setenv("PSN_MIRROR_RATIO", ratio)
+    rng = np.random.default_rng(77)
+    mirrored = 0
+    for i in range(24):
+        n = int(rng.integers(5, 300))
+        g = random_graph(rng, n, int(rng.integers(n, 12 * n)), maxcap=int(rng.choice([1, 4, 500])), maxcost=int(rng.choice([3, 50, 20000])),
+                         neg=bool(i % 3 == 0))
+        rc, tc, _, _ = capi.ssp(g)
+        assert rc == 0
+        r = solve_and_certify(solver, g)
+        assert r.total_cost == tc
+        mirrored += r.mirrored_replays
+        if r.mirrored_replays:
+            r2 = solver.solve(warm_start=True)
+            assert r2.total_cost == tc and r2.warm_started == 1 and r2.pushes == 0
+    for cfg, seed in ((0, 1), (0, 3), (1, 1)):
+        cl = pa.synth_cluster(cfg, seed)
+        net = pa.build_network(cl)
+        solver.upload(net)
+        solver.eval_costs(cl, net)
+        r = solver.solve()
+        assert r.total_cost == _gold(cfg, seed)["optimal_cost"]
+        og = synth.build_graph(synth.make_cluster(cfg, seed))
+        assert capi.check(og, solver.residual(), solver.prices(), scale=solver.price_scale())[:2] == (0, r.total_cost)
+        mirrored += r.mirrored_replays
+        assert r.mirrored_replays > 0 or ratio == "12"
+    assert mirrored > 0
