@@ -46,20 +46,59 @@ def algorithmic_bytes(r, kind):
     return r.algorithmic_bytes
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE in KiB per dispatch; FETCH_SIZE doubled, as gfx950 tallies 128-byte
-    read requests as 64 bytes).  None when no profile is committed."""
-    import csv
+def profile_files():
+    """The latest committed profile set: (PMC pass summary, kernel-trace statistics of the same run)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_write.csv")))
     if not files:
         return None, None
-    for row in csv.DictReader(open(files[-1])):
+    stats = files[-1].replace("pmc_fetch_write.csv", "bench_kernel_stats.csv")
+    return files[-1], (stats if os.path.exists(stats) else None)
+
+
+def check_profile_matches_library():
+    """The committed counter pass must come from a build that launches the kernels this build
+    launches: a profile of another solver would put another run's bytes over this run's time.
+    Raises SystemExit naming what differs (PSN_BENCH_ALLOW_STALE_PROFILE=1: report it instead)."""
+    import csv
+    pmc, _ = profile_files()
+    if pmc is None:
+        return "no profile committed"
+    want = set(pa.load_library().psn_kernel_list().decode().split(","))
+    have = {row["kernel"].split("::")[-1] for row in csv.DictReader(open(pmc)) if row["kernel"]}
+    missing = sorted(want - have)
+    if missing:
+        msg = f"{os.path.basename(pmc)} has no counters for {missing}: it was taken from another build of the solver (psn_version {pa.load_library().psn_version()})"
+        if os.environ.get("PSN_BENCH_ALLOW_STALE_PROFILE") != "1":
+            raise SystemExit("bench.py: stale profile: " + msg + "; run tools/measure.sh, commit the summaries under profiles/ (or set PSN_BENCH_ALLOW_STALE_PROFILE=1)")
+        return msg
+    return None
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in KiB per dispatch; FETCH_SIZE doubled, as gfx950 tallies 128-byte
+    read requests as 64 bytes), with where the figure comes from: the profile's file, its dispatch
+    count for the kernel and, from the kernel trace of the same profiled run, that run's launch
+    count and average duration.  None when no profile is committed."""
+    import csv
+    pmc, stats = profile_files()
+    if pmc is None:
+        return None, None
+    src = {"file": os.path.basename(pmc)}
+    traffic = None
+    for row in csv.DictReader(open(pmc)):
         if row["kernel"].endswith(kernel):
             f, w = float(row["FETCH_SIZE_per_dispatch"]), float(row["WRITE_SIZE_per_dispatch"])
-            return int((2 * f + w) * 1024), os.path.basename(files[-1])
-    return None, None
+            traffic = int((2 * f + w) * 1024)
+            src["pmc_dispatches"] = int(float(row["dispatches"]))
+    if stats:
+        for row in csv.DictReader(open(stats)):
+            if row["Name"].split("(")[0].endswith(kernel):
+                src["trace_file"] = os.path.basename(stats)
+                src["trace_launches"] = int(row["Calls"])
+                src["trace_avg_launch_us"] = round(float(row["AverageNs"]) / 1e3, 2)
+    return traffic, src
 
 
 def machine_uuid(i):
@@ -84,7 +123,12 @@ def service_rounds(config_id, seed, device, churn_rounds=2):
         d = {"round_ms": round(st.total_ms, 2), "wall_ms": round(wall_ms, 2), "build_ms": round(st.build_ms, 2), "upload_ms": round(st.upload_ms, 2),
              "update_ms": round(st.update_ms, 2), "solve_ms": round(st.solve_ms, 2), "extract_ms": round(st.extract_ms, 2),
              "warm": int(st.last_round_warm), "deltas": n_deltas, "cost": int(st.total_cost),
-             "patched_arcs": int(st.patched_arcs), "cap_updates": int(st.cap_updates), "supply_updates": int(st.supply_updates)}
+             "patched_arcs": int(st.patched_arcs), "cap_updates": int(st.cap_updates), "supply_updates": int(st.supply_updates),
+             # why a warm solve costs what it does: the epsilon its first phase ran at, the units of excess on the
+             # work list when its first round started, and the replays (one global update + 12 rounds each) it took
+             "solve": {"device_ms": round(st.solve_device_ms, 2), "first_eps_log2": int(st.solve_first_eps_log2), "first_units": int(st.solve_first_units),
+                       "phases": int(st.solve_refines), "replays": int(st.solve_replays), "last_phase_replays": int(st.solve_last_phase_replays),
+                       "rounds": int(st.solve_rounds), "global_updates": int(st.solve_global_updates), "pushes": int(st.solve_pushes)}}
         if moved is not None:
             d["migrated_or_preempted"] = moved
         return d
@@ -124,6 +168,19 @@ def service_rounds(config_id, seed, device, churn_rounds=2):
             wall = (time.perf_counter() - t0) * 1e3
             moved = int(np.isin(d_type, (int(ChangeType.MIGRATE), int(ChangeType.PREEMPT))).sum())
             rounds.append((f"churn{rnd}", part(s.stats(), wall, int(d_uid.shape[0]), moved)))
+        # one more round in which only pods change (5 % replaced, no machine re-priced, none taken out): no arc
+        # cost moves, so the kept prices are violated nowhere but at the arcs of the new tasks
+        ch = network.churn_round(cl, config_id, seed, churn_rounds + 1)
+        for i, t in enumerate(ch.tasks_replaced):
+            s.TaskRemoved(int(uids[t]))
+            uids[t] = nxt + i
+            task_class[t], task_job[t] = ch.new_class[i], ch.new_job[i]
+            e = int(ch.new_class[i])
+            s.TaskSubmitted(int(uids[t]), f"job-{int(ch.new_job[i]):06d}", int(cl.req_cpu[e]), int(cl.req_mem[e]))
+        t0 = time.perf_counter()
+        d_uid, d_type, _ = s.schedule_arrays()
+        wall = (time.perf_counter() - t0) * 1e3
+        rounds.append(("churn_pods_only", part(s.stats(), wall, int(d_uid.shape[0]), int(np.isin(d_type, (int(ChangeType.MIGRATE), int(ChangeType.PREEMPT))).sum()))))
         allocs_warm = pa.load_library().psn_debug_alloc_count() - allocs_before
     # the last churned cluster from scratch: same optimum, and what a cold solve of it costs
     cl2 = pa.network.Cluster(cl.layout, cl.cap_cpu, cl.cap_mem, used_cpu, used_mem, cl.req_cpu, cl.req_mem, task_class, task_job, cl.slots)
@@ -141,8 +198,16 @@ def service_rounds(config_id, seed, device, churn_rounds=2):
     out["cold_solve_of_last_churned_cluster_ms"] = round(rc.solve_ms, 2)
     out["warm_equals_cold_cost"] = bool(rc.total_cost == rounds[-1][1]["cost"])
     out["allocations_during_warm_rounds"] = int(allocs_warm)
-    warm_ms = float(np.mean([p["solve_ms"] for name, p in rounds[1:]]))
+    warm_ms = float(np.mean([p["solve"]["device_ms"] for name, p in rounds[1:1 + churn_rounds]]))
     out["warm_over_cold_solve"] = round(warm_ms / max(rc.solve_ms, 1e-9), 3)
+    out["cold_solve_of_last_churned_cluster"] = {"device_ms": round(rc.solve_ms, 2), "first_eps_log2": rc.first_eps_log2, "first_units": rc.first_units,
+                                                  "phases": rc.refines, "replays": rc.replays, "last_phase_replays": rc.last_phase_replays,
+                                                  "rounds": rc.rounds, "global_updates": rc.global_updates, "pushes": rc.pushes}
+    out["why_warm_is_not_cheaper"] = ("a solve is its replays (a global update over the whole network + 12 rounds, about half a millisecond at "
+                                      "10 000 machines); re-priced machines with free slots are genuinely cheaper or dearer by hundreds of cost "
+                                      "units, so the kept prices are violated by that much, the scaling resumes near the epsilon a cold solve "
+                                      "starts at and runs the same phases; it moves a third of the pushes in as many replays.  With only pods "
+                                      "replaced (churn_pods_only) no cost moves and the first epsilon is small")
     return out, (cl2, out_mask)
 
 
@@ -166,6 +231,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libpsn has no CPU path")
+    stale_profile = check_profile_matches_library() if int(os.environ.get("RANK", "0")) == 0 else None
     # PSN_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share
     # devices, collectives go through host tensors); the measured configuration is nccl (= RCCL), one GPU per rank.
     backend = os.environ.get("PSN_BENCH_BACKEND", "nccl")
@@ -249,17 +315,30 @@ def main():
         m1 = bnet[0].m if bnet else 533_200
         bplace = torch.empty((len(mine), P1), dtype=torch.int32, device="cuda")
 
+        bparts = {"price_ms": 0.0, "solve_ms": 0.0, "extract_ms": 0.0, "gather_ms": 0.0}
+
         def bstep():
+            t_a = time.perf_counter()
             for s1, c1, n1 in zip(bsol, bcl, bnet):
                 s1.eval_costs(c1, n1)
+            t_b = time.perf_counter()
             rs = pbatch.solve_batch(bsol) if bsol else []
+            t_c = time.perf_counter()
             for i, s1 in enumerate(bsol):
                 s1.placements_into(bplace[i].data_ptr())
+            torch.cuda.synchronize()
+            t_d = time.perf_counter()
             allp = pbatch.all_gather_placements(bplace if backend == "nccl" else bplace.cpu(), B, world, rank)
+            torch.cuda.synchronize()
+            t_e = time.perf_counter()
+            for key, dt in (("price_ms", t_b - t_a), ("solve_ms", t_c - t_b), ("extract_ms", t_d - t_c), ("gather_ms", t_e - t_d)):
+                bparts[key] += dt * 1e3
             return rs, allp
 
         bstep()
         fence()
+        for key in bparts:
+            bparts[key] = 0.0
         tb = time.perf_counter()
         bsteps = 3
         for _ in range(bsteps):
@@ -271,6 +350,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             bel = float(t.item())
         bcosts = pbatch.all_gather_costs([r_.total_cost for r_ in brs], B, world, rank, device=cdev)
+        # this rank's share of a batch step, part by part (host clock; the gather includes waiting for the slowest rank)
+        my_parts = torch.tensor([bparts[k_] / bsteps for k_ in ("price_ms", "solve_ms", "extract_ms", "gather_ms")], dtype=torch.float64, device=cdev)
+        if world > 1:
+            all_parts = [torch.empty_like(my_parts) for _ in range(world)]
+            dist.all_gather(all_parts, my_parts)
+        else:
+            all_parts = [my_parts]
+        per_rank = [{"rank": i_, "networks": len(pbatch.shard(B, world, i_)), "price_ms": round(float(p_[0]), 2), "solve_ms": round(float(p_[1]), 2),
+                     "extract_ms": round(float(p_[2]), 2), "gather_ms": round(float(p_[3]), 2)} for i_, p_ in enumerate(all_parts)]
         # the checker: some of this rank's networks against the CPU oracle (outside every timed region)
         checked = 0
         if args.batch_check > 0:
@@ -288,7 +376,7 @@ def main():
                      "graphs": B, "n_gpus": world, "scaling": "strong", "graphs_per_s": round(B * bsteps / bel, 1),
                      "arcs_per_s": round(m1 * B * bsteps / bel, 1), "ms_per_batch": round(bel / bsteps * 1e3, 2),
                      "placed_total": int((ballp >= 0).sum().item()), "cost_checksum": int(sum(bcosts) % (1 << 61)),
-                     "oracle_checked": checked}
+                     "oracle_checked": checked, "per_rank": per_rank}
         for s1 in bsol:
             s1.close()
 
@@ -321,7 +409,8 @@ def main():
             real = bytes_total - 16 * skips
             return {"bound": "hbm", "kernel": "k_" + kind, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from " + str(traffic_src),
+                    "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 of the committed counter pass",
+                    "traffic_source": traffic_src, "traffic_source_problem": stale_profile,
                     "launches": calls, "avg_launch_us": round(avg_us, 2), "kernel_total_ms": round(ms, 2),
                     "algorithmic_bytes_per_launch": int(bytes_total / calls),
                     # both currencies: the 20-bytes-per-arc-scan rule, and what HBM saw (PMC pass of the committed profile)
@@ -366,7 +455,10 @@ def main():
                               "pushes": int(st.pushes), "relabels": int(st.relabels), "global_updates": int(st.global_updates)}
             best = min(rows, key=lambda k: rows[k]["solve_ms"])
             cpu = {"value": rows[best]["arcs_per_s"], "unit": "arcs/s", "cores": 1, "kind": "port",
-                   "solve_ms": rows[best]["solve_ms"], "variant": best, "variants": rows, "pinned_to_one_core": pinned,
+                   "solve_ms": rows[best]["solve_ms"],
+                   "variant": best + "; not given to the CPU port: the GPU solver's early phase ends (a sequential solver's last units "
+                              "of a phase cost a few hundred operations each, not a pair of launches) and its replays on the reversed network",
+                   "variants": rows, "pinned_to_one_core": pinned,
                    "host_cores_total": os.cpu_count(), "optimal_cost": int(all_costs[0]), "build": capi.build_flags(),
                    "sample": f"full psn-synth-v1 config {args.config} seed {seed} network, single-thread cost-scaling "
                              f"push-relabel (oracle/psn_oracle.c), median of 3 solves per variant, the faster variant reported"}
@@ -380,12 +472,14 @@ def main():
                                    f"n={net.n} vertices, m={net.m} forward arcs, one network per GPU (seed = 1 + rank)",
                        "graphs_per_step": world, "alpha": 16, "rounds_per_global_update": 12},
             "solve_ms": round(solve_ms, 3), "solve_ms_min": round(min(solve_all), 3), "solve_ms_max": round(max(solve_all), 3),
+            "solve_ms_p10_p50_p90": [round(float(np.percentile(solve_all, q)), 3) for q in (10, 50, 90)],
             "optimal_cost": all_costs, "tasks_placed": placed_all,
             "upload_s_not_timed": round(upload_s, 4),
             "counters": {"arc_scans": r.arc_scans, "gu_arc_scans": r.gu_arc_scans, "gu_arc_skips": r.gu_arc_skips, "arc_skips": r.arc_skips, "sat_arc_scans": r.sat_arc_scans,
                          "pushes": r.pushes, "relabels": r.relabels, "vertex_visits": r.vertex_visits, "rounds": r.rounds,
                          "gu_iterations": r.gu_iterations, "global_updates": r.global_updates, "refines": r.refines,
-                         "launches": r.launches},
+                         "launches": r.launches, "replays": r.replays, "mirrored_replays": r.mirrored_replays,
+                         "last_phase_replays": r.last_phase_replays},
             "solve_algorithmic_GBps": round(r.algorithmic_bytes / (solve_ms * 1e-3) / 1e9, 1),
             "roofline": roof, "cpu_baseline": cpu, "what_if_batch": batch_out, "c3": c3,
         }

@@ -86,6 +86,11 @@ typedef struct psn_result {
     int32_t warm_started;    /* 1: the solve resumed from the kept flow and prices; 0: it started cold (no
                               * PSN_WARM_START, nothing solved before, or an update invalidated the kept state) */
     int32_t mirrored_replays; /* replays run on the reversed network (deficits pushed towards the excesses) */
+    uint64_t replays;        /* passes over the fixed launch sequence (one global update + a batch of rounds each) */
+    uint64_t first_units;    /* units of excess at the work-list vertices when the first round of the solve started,
+                              * i.e. what the first phase's saturation (plus, warm, the changes since the last solve) set free */
+    int32_t first_eps_log2;  /* log2 of the epsilon the first phase ran at (scaled costs) */
+    int32_t last_phase_replays; /* replays spent at epsilon = 1 */
 } psn_result;
 
 #define PSN_WARM_START 1u    /* psn_solve: keep prices and flow from the previous solve */
@@ -98,6 +103,10 @@ typedef struct psn_layout {
 } psn_layout;
 
 int psn_version(void);
+/* Names of the kernels one solve launches (comma separated, without namespace or arguments), so that a
+ * profile taken from one build can be told from a profile of another: bench.py refuses to quote HBM
+ * traffic from a committed counter pass whose kernel list differs. */
+const char *psn_kernel_list(void);
 const char *psn_strerror(int code);
 const char *psn_last_error(const psn_ctx *ctx);
 

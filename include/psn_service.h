@@ -113,6 +113,10 @@ typedef struct psn_svc_stats {
     double total_ms;         /* last Schedule from entry to return, host clock */
     int64_t tasks_deferred;  /* last Schedule: placements not admitted because the request no longer fitted next
                                 to what other classes were given on that machine in the same round */
+    /* the solve of the last Schedule (psn_result fields of the same names) */
+    int64_t solve_replays, solve_last_phase_replays, solve_refines, solve_rounds, solve_global_updates, solve_pushes,
+        solve_first_units, solve_first_eps_log2;
+    double solve_device_ms;
 } psn_svc_stats;
 
 int psn_svc_create(const psn_svc_config *cfg, psn_svc **out);

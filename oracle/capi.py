@@ -95,8 +95,8 @@ CS_EPS_PERCENTILE, CS_PRICE_REFINE, CS_COVER_SCALE = 1, 2, 4
 BASELINE_VARIANTS = {
     "plain (eps from max cost, alpha 12)": {},
     "tuned (eps from 90th-percentile cost, alpha 16, price refinement)": {"alpha": 16, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE},
-    "tuned + cost scale from the cycle-length bound, alpha 16": {"alpha": 16, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE | CS_COVER_SCALE},
-    "tuned + cost scale from the cycle-length bound, alpha 8 (as the GPU solver)": {"alpha": 8, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE | CS_COVER_SCALE},
+    "tuned + cost scale from the cycle-length bound, alpha 16 (as the GPU solver)": {"alpha": 16, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE | CS_COVER_SCALE},
+    "tuned + cost scale from the cycle-length bound, alpha 8": {"alpha": 8, "flags": CS_EPS_PERCENTILE | CS_PRICE_REFINE | CS_COVER_SCALE},
 }
 
 

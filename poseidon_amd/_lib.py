@@ -22,7 +22,7 @@ PSN_CFG_EPS_FROM_MAX = 4
 KT_NAMES = ["push", "gu_expand", "relabel_compact", "saturate", "other"]
 
 EXPORTS = [
-    "psn_version", "psn_strerror", "psn_last_error", "psn_create", "psn_destroy",
+    "psn_version", "psn_kernel_list", "psn_strerror", "psn_last_error", "psn_create", "psn_destroy",
     "psn_upload_csr", "psn_eval_costs", "psn_update_caps", "psn_update_supplies", "psn_solve",
     "psn_get_flow", "psn_get_residual", "psn_get_prices", "psn_get_costs", "psn_get_placements",
     "psn_placements_device_ptr", "psn_get_placements_device", "psn_kernel_times", "psn_debug_trace",
@@ -58,7 +58,8 @@ class Result(C.Structure):
                 ("gu_relaxations", C.c_uint64), ("sat_arc_scans", C.c_uint64), ("rounds", C.c_uint64),
                 ("gu_iterations", C.c_uint64), ("global_updates", C.c_uint64), ("launches", C.c_uint64),
                 ("solve_ms", C.c_double), ("gu_arc_skips", C.c_uint64), ("arc_skips", C.c_uint64),
-                ("warm_started", C.c_int32), ("mirrored_replays", C.c_int32)]
+                ("warm_started", C.c_int32), ("mirrored_replays", C.c_int32), ("replays", C.c_uint64),
+                ("first_units", C.c_uint64), ("first_eps_log2", C.c_int32), ("last_phase_replays", C.c_int32)]
 
 
 class Layout(C.Structure):
@@ -79,6 +80,7 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32
     lib.psn_version.restype = C.c_int
+    lib.psn_kernel_list.restype = C.c_char_p
     lib.psn_strerror.restype = C.c_char_p
     lib.psn_strerror.argtypes = [C.c_int]
     lib.psn_last_error.restype = C.c_char_p

@@ -479,7 +479,10 @@ int ceil_log2(i64 x) {
 
 extern "C" {
 
-int psn_version(void) { return 100; }
+int psn_version(void) { return 300; }
+const char *psn_kernel_list(void) {
+    return "k_begin,k_flip,k_saturate,k_gu_init,k_gu_expand,k_gu_apply,k_relabel_compact,k_push";
+}
 
 const char *psn_strerror(int code) {
     switch (code) {
@@ -1190,6 +1193,7 @@ static Ctrl solve_init(psn_ctx *c, bool warm, const i64 *h_scalar) {
     init.eps_shift = shift0;
     init.eps = (i64)1 << shift0;
     init.need_sat = 1;
+    init.first_units = ~0u;
     // replays on the reversed network (see Orient in the kernels and k_begin): from an epsilon of 64 cost units down
     init.mirror_max_shift = ceil_log2(g.scale) + 6;
     init.mirror_ratio = 3;  // in quarters: as soon as the deficits sit at no more than 4/3 as many vertices as this side has work items
@@ -1218,7 +1222,7 @@ static int solve_finish(psn_ctx *c, hipStream_t s, i64 *h_cost, unsigned long lo
     return PSN_OK;
 }
 static void solve_report(psn_ctx *c, psn_result *out, int status, i64 cost, const unsigned long long *h_tally, long long replays,
-                         int launches_per_replay, float ms, bool warm) {
+                         int launches_per_replay, float ms, bool warm, int first_shift) {
     out->warm_started = warm ? 1 : 0;
     out->total_cost = cost;
     out->status = status;
@@ -1238,6 +1242,10 @@ static void solve_report(psn_ctx *c, psn_result *out, int status, i64 cost, cons
     out->gu_arc_skips = h_tally[kTallyGuSkips];
     out->arc_skips = h_tally[kTallySkips];
     out->mirrored_replays = (int32_t)c->h_ctrl->tally_mirror;
+    out->replays = (uint64_t)replays;
+    out->first_units = c->h_ctrl->first_units == ~0u ? 0 : c->h_ctrl->first_units;
+    out->last_phase_replays = (int32_t)c->h_ctrl->last_phase_replays;
+    out->first_eps_log2 = first_shift;
     c->solved = status == PSN_OK;
 }
 
@@ -1256,6 +1264,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     if (rc != PSN_OK) return rc;
     HIPCHK(c, hipStreamSynchronize(s));
     if ((rc = solve_start(c, s, warm, h_scalar)) != PSN_OK) return rc;
+    const int first_shift = c->h_ctrl->eps_shift;
     // ---- replay until done
     long long max_replays = 200000;
     if (const char *ev = std::getenv("PSN_MAX_REPLAYS")) max_replays = std::max(1, atoi(ev));  // development: stop a solve half way (PSN_ELIMIT)
@@ -1328,7 +1337,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     HIPCHK(c, hipStreamSynchronize(s));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    solve_report(c, out, status, h_cost, h_tally, replays, c->launches_per_replay, ms, warm);
+    solve_report(c, out, status, h_cost, h_tally, replays, c->launches_per_replay, ms, warm, first_shift);
     if (std::getenv("PSN_DEBUG_SOLVE"))
         fprintf(stderr, "psn_solve: %s first shift %d (max violation %lld) refines %d replays %lld rounds %llu gus %llu gu_iters %llu pushes %llu relabels %llu %.2f ms\n",
                 warm ? "warm" : "cold", ceil_log2(std::max<i64>(1, warm ? h_scalar[1] : h_scalar[2] * g.scale)) - c->cfg.alpha_log2, (long long)h_scalar[1], out->refines, replays,
@@ -1494,7 +1503,8 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
         if (m[i]->g.dbg_cnt) GCHK(hipMemsetAsync(m[i]->g.dbg_cnt, 0, sizeof(unsigned), s));
     GCHK(hipStreamSynchronize(s));
     std::memcpy(h_scalar.data(), gc->h_scalars, G * kScalarSlots * sizeof(i64));
-    for (size_t i = 0; i < G; ++i) gc->h_ctrls[i] = solve_init(m[i], warm[i], &h_scalar[i * kScalarSlots]);
+    std::vector<int> first_shifts(G, 0);
+    for (size_t i = 0; i < G; ++i) { gc->h_ctrls[i] = solve_init(m[i], warm[i], &h_scalar[i * kScalarSlots]); first_shifts[i] = gc->h_ctrls[i].eps_shift; }
     GCHK(hipMemcpyAsync(gc->d_ctrls, gc->h_ctrls, G * sizeof(Ctrl), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_ctrl_scatter_group, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, s, gc->d_graphs, gc->d_ctrls, (int)G);
     t_b = now();
@@ -1560,7 +1570,7 @@ int solve_group(const std::vector<psn_ctx *> &m, uint32_t flags, psn_result *con
     if (dbg_t) fprintf(stderr, "group of %zu (%s): prepare %.2f capture+instantiate %.2f replays(%lld) %.2f finish %.2f ms\n", G, fresh ? "new" : "cached", t_b - t_a, t_c - t_b, replays, t_d - t_c, t_e - t_d);
     rc = PSN_OK;
     for (size_t i = 0; i < G; ++i) {
-        solve_report(m[i], out[i], status[i], h_cost[i], &h_tally[i * kTallyN], replays, gc->launches, ms, warm[i] != 0);
+        solve_report(m[i], out[i], status[i], h_cost[i], &h_tally[i * kTallyN], replays, gc->launches, ms, warm[i] != 0, first_shifts[i]);
         if (status[i] != PSN_OK) {
             (void)fail(m[i], status[i], h_scalar[i * kScalarSlots + kSupplySumSlot] != 0 ? "supplies do not sum to zero" : "solve did not converge");
             if (rc == PSN_OK) rc = status[i];

@@ -57,6 +57,8 @@ struct Ctrl {
     int mirror_max_shift;   // replays may run mirrored in phases with eps_shift <= this (-1: never)
     int mirror_ratio;       // ... changing sides when (vertices holding a deficit) * mirror_ratio / 4 <= work items of the current side (0: never)
     unsigned long long tally_mirror;  // replays run mirrored
+    unsigned first_units;             // units of excess on the work list when the solve's first round started (~0: not yet)
+    unsigned last_phase_replays;      // replays begun at epsilon = 1
 };
 
 // Plain-pointer view of one flow network in HBM (struct of arrays).

@@ -333,6 +333,9 @@ __device__ __forceinline__ void seg_note(const DevGraph &g, int hub, int r, i64 
     amax64(&g.seg_add[par][s], key);
 }
 
+constexpr int kCntUnits = 2;     // work-list counter slot: units of excess at the listed vertices (a vertex counts for at most 2^16 - 1)
+constexpr int kCntDeficits = 3;  // work-list counter slot: vertices that hold a deficit (hubs included)
+
 // ------------------------------------------------------------------- orientation
 // The sweeps can work on the network as it is or on its mirror image: every arc reversed, supplies
 // and prices negated.  In the residual CSR the mirror needs no second copy: the reverse of arc a
@@ -629,6 +632,7 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     if (!on) return;
     const Orient o = orient_of(g, mirror);
     if (blockIdx.x == 0 && threadIdx.x < 4) ct->list_cnt[(k + 1) & 1][threadIdx.x] = 0;
+    if (k == 0 && blockIdx.x == 0 && threadIdx.x == 0 && ct->first_units == ~0u) ct->first_units = cnt[kCntUnits];
     if (nlow + nseg == 0) return;
     if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
         const unsigned i = aadd32(g.dbg_cnt, 1u);
@@ -673,8 +677,6 @@ __device__ __forceinline__ HubTurn hub_fetch(const DevGraph &g, int hv) {
     h.r0 = g.row[hv]; h.r1 = g.row[hv + 1]; h.seg1 = g.seg1_of[hv];
     return h;
 }
-constexpr int kCntUnits = 2;     // work-list counter slot: units of excess at the listed vertices (a vertex counts for at most 2^16 - 1)
-constexpr int kCntDeficits = 3;  // work-list counter slot: vertices that hold a deficit (hubs included)
 __device__ __forceinline__ unsigned excess_units(i64 e) { return e > 0 ? (unsigned)(e < 65535 ? e : 65535) : 0u; }
 // The thread that looks after a hub relabels it and resets its candidate.
 __device__ __forceinline__ void hub_decide(const DevGraph &g, HubTurn &h, bool do_relabel, i64 eps, unsigned rot, Tally &t, unsigned *cnt) {
@@ -1449,6 +1451,7 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
         }
     }
     if (ct->mirror) ct->tally_mirror++;
+    if (ct->eps_shift == 0) ct->last_phase_replays++;
 }
 
 // Negates prices and excesses in place when the orientation changes (or, with `unflip`, when a

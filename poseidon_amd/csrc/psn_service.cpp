@@ -961,6 +961,9 @@ int64_t psn_svc_schedule(psn_svc *s) {
     s->st.last_round_warm = warm ? 1 : 0;
     if (warm) ++s->st.warm_rounds;
     s->st.total_cost = res.total_cost;
+    s->st.solve_replays = (i64)res.replays; s->st.solve_last_phase_replays = res.last_phase_replays; s->st.solve_refines = res.refines;
+    s->st.solve_rounds = (i64)res.rounds; s->st.solve_global_updates = (i64)res.global_updates; s->st.solve_pushes = (i64)res.pushes;
+    s->st.solve_first_units = (i64)res.first_units; s->st.solve_first_eps_log2 = res.first_eps_log2; s->st.solve_device_ms = res.solve_ms;
     // ---- placements -> deltas
     const double t0 = now_ms();
     std::vector<int32_t> place((size_t)s->P, -1);

@@ -33,7 +33,10 @@ class SvcStats(C.Structure):
                 ("build_ms", C.c_double), ("upload_ms", C.c_double), ("update_ms", C.c_double),
                 ("solve_ms", C.c_double), ("extract_ms", C.c_double),
                 ("total_cost", C.c_int64), ("last_round_warm", C.c_int32),
-                ("tasks_running", C.c_int64), ("total_ms", C.c_double), ("tasks_deferred", C.c_int64)]
+                ("tasks_running", C.c_int64), ("total_ms", C.c_double), ("tasks_deferred", C.c_int64),
+                ("solve_replays", C.c_int64), ("solve_last_phase_replays", C.c_int64), ("solve_refines", C.c_int64),
+                ("solve_rounds", C.c_int64), ("solve_global_updates", C.c_int64), ("solve_pushes", C.c_int64),
+                ("solve_first_units", C.c_int64), ("solve_first_eps_log2", C.c_int64), ("solve_device_ms", C.c_double)]
 
 
 class Selector(C.Structure):  # include/psn_service.h psn_selector

@@ -31,6 +31,10 @@ class SolveResult:
     arc_skips: int = 0
     warm_started: int = 0
     mirrored_replays: int = 0
+    replays: int = 0
+    first_units: int = 0
+    first_eps_log2: int = 0
+    last_phase_replays: int = 0
 
     @property
     def algorithmic_bytes(self) -> int:

@@ -13,7 +13,7 @@ Run from the repo root:  python tests/golden/make_golden.py
 then, optionally (tens of minutes):  python tests/golden/make_golden.py --nx-c1-only
 which adds the networkx cost of config 1 / seed 1 to the existing file;
   python tests/golden/make_golden.py --ssp-c2
-adds the successive-shortest-paths optimum of the config 2 networks (about half an hour each,
+adds the successive-shortest-paths optimum of the config 2 networks (about seven minutes each,
 single thread), so that the full-size golden cost rests on two C oracles that agree;
   python tests/golden/make_golden.py --c4
 writes psn_c4_costs.json: the cost-scaling optimum (certificate checked) and the CSR checksum of

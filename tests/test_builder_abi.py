@@ -106,3 +106,20 @@ def test_churn_generator_matches_the_oracle_spec():
                      (ch.machines_restat, och.machines_restat), (ch.new_used_cpu, och.new_used_cpu),
                      (ch.new_used_mem, och.new_used_mem), (ch.machines_out, och.machines_out)]:
             assert np.array_equal(a, b)
+
+
+def test_committed_profile_belongs_to_this_build():
+    """bench.py quotes HBM traffic from the latest committed counter pass and refuses one taken from
+    another build (its kernel list must cover psn_kernel_list()): checked here as well, so that a
+    change of the launch sequence without a new profile fails before any benchmark run does."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("psn_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    os.environ.pop("PSN_BENCH_ALLOW_STALE_PROFILE", None)
+    assert bench.check_profile_matches_library() is None
+    traffic, src = bench.pmc_traffic("k_push")
+    assert traffic > 0 and src["pmc_dispatches"] > 0 and src["trace_launches"] > 0 and src["trace_avg_launch_us"] > 0
+    assert set(pa.load_library().psn_kernel_list().decode().split(",")) >= {"k_push", "k_gu_expand", "k_relabel_compact", "k_flip"}
