@@ -470,7 +470,7 @@ def main():
             "dtype": "int64", "data": "synthetic" if backend == "nccl" else f"synthetic (rehearsal over {backend}: not a measurement)",
             "config": {"workload": f"psn-synth-v1 config {args.config}: {cl.layout.n_machines} machines / {P} pods, "
                                    f"n={net.n} vertices, m={net.m} forward arcs, one network per GPU (seed = 1 + rank)",
-                       "graphs_per_step": world, "alpha": 16, "rounds_per_global_update": 12},
+                       "graphs_per_step": world, "alpha": 16, "rounds_per_global_update": 14},
             "solve_ms": round(solve_ms, 3), "solve_ms_min": round(min(solve_all), 3), "solve_ms_max": round(max(solve_all), 3),
             "solve_ms_p10_p50_p90": [round(float(np.percentile(solve_all, q)), 3) for q in (10, 50, 90)],
             "optimal_cost": all_costs, "tasks_placed": placed_all,

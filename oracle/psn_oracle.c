@@ -610,19 +610,56 @@ int psn_oracle_check(i32 n, i64 m2, const i64 *row_off, const i32 *head, const i
  * 2 * |cover| arcs (and at most n).  The cover is the complement of the independent set
  * { v : every neighbour has a longer row than v, ties broken by id }; self-loops are ignored. */
 i64 psn_oracle_cycle_bound(i32 n, const i64 *row_off, const i32 *head) {
-    i64 cover = 0;
+    /* Sharper than 2 * |cover|: outside the cover no two vertices are adjacent, so between two cover
+     * vertices that follow each other on a simple cycle lies at most one other vertex.  Take a subset
+     * I of the cover no two members of which are adjacent or share a neighbour outside the cover: two
+     * members of I never follow each other on a cycle, so at most half of the cover vertices of a
+     * cycle are in I, and a cycle has at most 4 * |cover \ I| arcs.  I = cover vertices v such that
+     * (row length, id) of v is below that of every neighbour in the cover, and v is the smallest by
+     * that key among the cover neighbours of each of its neighbours outside the cover.  Two arcs
+     * between the same pair of vertices form a cycle of length 2, hence the floor. */
+    unsigned char *in_cover = (unsigned char *)calloc((size_t)n + 1, 1);
+    i32 *best = (i32 *)malloc(sizeof(i32) * ((size_t)n + 1));
+    if (!in_cover || !best) { free(in_cover); free(best); return (i64)n; }
+    i64 cover = 0, noni = 0;
+#define ROWLEN(x) (row_off[(x) + 1] - row_off[(x)])
+#define KEY_LT(a, b) (ROWLEN(a) < ROWLEN(b) || (ROWLEN(a) == ROWLEN(b) && (a) < (b)))
     for (i32 v = 0; v < n; ++v) {
-        const i64 dv = row_off[v + 1] - row_off[v];
         int out = 1;
         for (i64 a = row_off[v]; a < row_off[v + 1] && out; ++a) {
             const i32 u = head[a];
             if (u == v) continue;
-            const i64 du = row_off[u + 1] - row_off[u];
-            if (!(du > dv || (du == dv && u > v))) out = 0;
+            if (!KEY_LT(v, u)) out = 0;
         }
+        in_cover[v] = !out;
         cover += !out;
     }
-    return 2 * cover < (i64)n ? 2 * cover : (i64)n;
+    for (i32 w = 0; w < n; ++w) { /* smallest-keyed cover neighbour of every vertex outside the cover */
+        best[w] = -1;
+        if (in_cover[w]) continue;
+        for (i64 a = row_off[w]; a < row_off[w + 1]; ++a) {
+            const i32 u = head[a];
+            if (u == w || !in_cover[u]) continue;
+            if (best[w] < 0 || KEY_LT(u, best[w])) best[w] = u;
+        }
+    }
+    for (i32 v = 0; v < n; ++v) {
+        if (!in_cover[v]) continue;
+        int indep = 1;
+        for (i64 a = row_off[v]; a < row_off[v + 1] && indep; ++a) {
+            const i32 x = head[a];
+            if (x == v) continue;
+            if (in_cover[x]) { if (!KEY_LT(v, x)) indep = 0; }
+            else if (best[x] != v) indep = 0;
+        }
+        noni += !indep;
+    }
+#undef KEY_LT
+#undef ROWLEN
+    free(in_cover); free(best);
+    i64 bound = 2 * cover < (i64)n ? 2 * cover : (i64)n;
+    if (4 * noni < bound) bound = 4 * noni;
+    return bound < 2 ? 2 : bound;
 }
 
 /* Scaled-price certificate for an arbitrary cost multiplier `scale`: every residual arc has

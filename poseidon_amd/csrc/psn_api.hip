@@ -81,6 +81,10 @@ struct psn_ctx {
     int2 *d_pull_list = nullptr;
     unsigned *d_pull_cnt = nullptr;
     long long cover_size = 0, cover_cap = 0;
+    // ... and the part of the cover that is not in the independent subset (see k_cover_best), with its head-room
+    unsigned long long *d_cover_best = nullptr;
+    unsigned char *d_not_indep = nullptr;
+    long long noni_size = 0, noni_cap = 0;
     struct GroupCache *gcache = nullptr;  // lockstep group led by this context, kept between batch calls
     // the slot-block layout the cost kernel last verified on the device (k_check_slot_layout re-reads
     // the pairing of every slot arc: 150 MB at 10 000 machines): valid for this upload until arcs are patched
@@ -179,7 +183,7 @@ void free_graph_buffers(psn_ctx *c) {
     ++c->upload_gen;
     c->uploaded = c->solved = false;
     c->d_place = c->d_slot_machine = nullptr;
-    c->d_in_cover = nullptr; c->d_cls = nullptr; c->d_lean_stop = nullptr; c->d_hub_of = nullptr; c->d_pull_list = nullptr; c->d_pull_cnt = nullptr; c->cover_size = c->cover_cap = 0;
+    c->d_in_cover = nullptr; c->d_cls = nullptr; c->d_lean_stop = nullptr; c->d_hub_of = nullptr; c->d_pull_list = nullptr; c->d_pull_cnt = nullptr; c->cover_size = c->cover_cap = 0; c->d_cover_best = nullptr; c->d_not_indep = nullptr; c->noni_size = c->noni_cap = 0;
     c->d_allow = nullptr; c->allow_words = c->allow_classes = 0; c->allow_on = false;
     c->place_count = c->slot_stride = c->slot_classes = 0;
 }
@@ -297,6 +301,48 @@ __global__ void k_cover_mark(const unsigned *row, int n, unsigned m2, const int 
         const unsigned dt = row[t + 1] - row[t], dh = row[h + 1] - row[h];
         if (!(dh > dt || (dh == dt && h > t))) in_cover[t] = 1;  // a neighbour that is not "larger": t cannot stay out
     }
+}
+// A sharper bound from the same cover C.  Between two cover vertices that follow each other on a
+// simple cycle lies at most one other vertex (the vertices outside C are pairwise non-adjacent), so
+// a cycle with k cover vertices has at most 2k arcs.  Let I be a subset of C no two members of which
+// are adjacent or share a neighbour outside C: two members of I cannot follow each other on a
+// cycle, so at most half of a cycle's cover vertices are in I, k <= 2 |C \ I|, and no simple cycle
+// has more than 4 |C \ I| arcs (two arcs between one pair of vertices are a cycle of 2).  I is taken
+// as the cover vertices v such that, with key(u) = (row length, id): every neighbour in C has a larger
+// key than v, and every neighbour w outside C has v as the smallest-keyed of w's cover neighbours
+// (so w borders no second member of I).  In a scheduling network I holds the unscheduled
+// aggregators (each task has one, the sink and the classes have larger rows), C \ I the classes
+// and the sink: 4 * 65 arcs instead of 2 * 2 065 at 10 000 machines - four bits of cost scale,
+// one refine phase.
+__device__ __forceinline__ unsigned long long cover_key(const unsigned *row, int v) {
+    return ((unsigned long long)(row[v + 1] - row[v]) << 32) | (unsigned)v;
+}
+__global__ void k_cover_best(const unsigned *row, int n, unsigned m2, const int *head, const int *tail, const unsigned char *in_cover,
+                             unsigned long long *best) {
+    for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < m2; a += gridDim.x * kBlock) {
+        const int t = tail[a], h = head[a];
+        if (h == t || (unsigned)h >= (unsigned)n) continue;
+        if (!in_cover[t] && in_cover[h]) {
+            const unsigned long long k = cover_key(row, h);
+            if (k < best[t]) __hip_atomic_fetch_min(&best[t], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // best only falls: a stale read just costs an atomic
+        }
+    }
+}
+__global__ void k_cover_indep(const unsigned *row, int n, unsigned m2, const int *head, const int *tail, const unsigned char *in_cover,
+                              const unsigned long long *best, unsigned char *not_indep) {
+    for (unsigned a = blockIdx.x * kBlock + threadIdx.x; a < m2; a += gridDim.x * kBlock) {
+        const int t = tail[a], h = head[a];
+        if (h == t || (unsigned)h >= (unsigned)n || !in_cover[t]) continue;
+        const unsigned long long kt = cover_key(row, t);
+        const bool ok = in_cover[h] ? kt < cover_key(row, h) : best[h] == kt;
+        if (!ok) not_indep[t] = 1;
+    }
+}
+__global__ void k_cover_count_noni(const unsigned char *in_cover, const unsigned char *not_indep, int n, unsigned *out) {
+    unsigned c = 0;
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) c += in_cover[v] && not_indep[v];
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0 && c) __hip_atomic_fetch_add(out, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Rows made of aligned groups of 8 parallel arcs (the 8 slot arcs between a task class and a
 // machine, seen from either end) let the expansion sweep fetch one head per lane instead of eight
@@ -450,6 +496,17 @@ int launch_cover(psn_ctx *c) {
     if (g.m2) hipLaunchKernelGGL(k_cover_mark, dim3(kGrid), dim3(kBlock), 0, c->stream, g.row, g.n, g.m2, g.head, g.tail, c->d_in_cover);
     hipLaunchKernelGGL(k_cover_count, dim3(std::max(1, std::min(256, (g.n + kBlock - 1) / kBlock))), dim3(kBlock), 0, c->stream, c->d_in_cover, g.n, d_cnt);
     HIPCHK(c, hipMemcpyAsync(c->h_flag + 2, d_cnt, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    // the cover vertices outside the independent subset (count on its way to h_flag[3])
+    unsigned *d_cnt2 = d_cnt + 1;
+    HIPCHK(c, hipMemsetAsync(c->d_cover_best, 0xFF, sizeof(unsigned long long) * (size_t)g.n, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_not_indep, 0, (size_t)g.n, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_cnt2, 0, sizeof(unsigned), c->stream));
+    if (g.m2) {
+        hipLaunchKernelGGL(k_cover_best, dim3(kGrid), dim3(kBlock), 0, c->stream, g.row, g.n, g.m2, g.head, g.tail, c->d_in_cover, c->d_cover_best);
+        hipLaunchKernelGGL(k_cover_indep, dim3(kGrid), dim3(kBlock), 0, c->stream, g.row, g.n, g.m2, g.head, g.tail, c->d_in_cover, c->d_cover_best, c->d_not_indep);
+    }
+    hipLaunchKernelGGL(k_cover_count_noni, dim3(std::max(1, std::min(256, (g.n + kBlock - 1) / kBlock))), dim3(kBlock), 0, c->stream, c->d_in_cover, c->d_not_indep, g.n, d_cnt2);
+    HIPCHK(c, hipMemcpyAsync(c->h_flag + 3, d_cnt2, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     // the other table that follows from the heads alone: where rows stop being groups of parallel arcs
     const int gvn = std::max(1, std::min(kGrid, (g.n + kBlock - 1) / kBlock));
     hipLaunchKernelGGL(k_lean_init, dim3(gvn), dim3(kBlock), 0, c->stream, g.row, g.n, c->d_lean_stop);
@@ -461,10 +518,14 @@ int launch_cover(psn_ctx *c) {
 }
 // The cost scale that goes with a cover of `cover` vertices, with room for the cover to grow a
 // little (tasks and jobs that arrive later) before the scale has to change.
-void scale_for_cover(psn_ctx *c, long long cover) {
+void scale_for_cover(psn_ctx *c, long long cover, long long noni) {
     c->cover_size = cover;
     c->cover_cap = cover + std::max<long long>(64, cover / 8);
+    c->noni_size = noni;
+    c->noni_cap = noni + std::max<long long>(16, noni / 8);
     i64 len = std::min<i64>((i64)c->g.n, 2 * (i64)c->cover_cap);  // no simple cycle is longer
+    if (!std::getenv("PSN_SCALE_COVER")) len = std::min<i64>(len, 4 * (i64)c->noni_cap);  // (development: the plain cover bound)
+    len = std::max<i64>(len, 2);
     if (std::getenv("PSN_SCALE_N")) len = c->g.n;                 // diagnostics: the textbook scale n + 1
     c->g.scale = len + 1;
 }
@@ -509,7 +570,7 @@ int psn_create(const psn_config *cfg, psn_ctx **out) {
     if (!c) return PSN_ENOMEM;
     if (cfg) c->cfg = *cfg;
     if (c->cfg.alpha_log2 <= 0 || c->cfg.alpha_log2 > 8) c->cfg.alpha_log2 = kDefaultAlphaLog2;
-    c->rounds = c->cfg.rounds_per_batch > 0 ? c->cfg.rounds_per_batch : 12;
+    c->rounds = c->cfg.rounds_per_batch > 0 ? c->cfg.rounds_per_batch : kDefaultRounds;
     if (const char *ev = std::getenv("PSN_ROUNDS")) c->rounds = std::max(1, std::min(64, atoi(ev)));  // tuning aid
     if (c->rounds & 1) ++c->rounds;  // list parity must be the same at every replay start
     if (c->rounds > 62) c->rounds = 62;
@@ -609,7 +670,7 @@ static int setup_rows(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off)
     A(d_row, n + 1) A(d_head, m2 + kArcPad) A(c->d_cost, m2 + kArcPad) A(d_rev, m2 + kArcPad) A(d_tail, m2) A(c->d_ocap, m2 + kArcPad) A(d_cls, n) A(d_hub_of, n) A(d_hub_vertex, kMaxHubs)
     A(d_hub_row0, kMaxHubs) A(d_hub_seg0, kMaxHubs) A(d_seg1_of, n) A(g.seg_scan, n_hub_segs) A(g.seg_add[0], n_hub_segs) A(g.seg_add[1], n_hub_segs)
     A(g.cap, m2 + kArcPad) A(g.rcap, m2 + kArcPad) A(g.price, n) A(g.excess, n) A(g.cand, n) A(g.dist, n)
-    A(c->d_supply, n) A(c->d_scalar, kScalarSlots) A(c->d_in_cover, n) A(c->d_lean_stop, n) A(c->d_pull_list, n) A(c->d_pull_cnt, 1)
+    A(c->d_supply, n) A(c->d_scalar, kScalarSlots) A(c->d_in_cover, n) A(c->d_cover_best, n) A(c->d_not_indep, n) A(c->d_lean_stop, n) A(c->d_pull_list, n) A(c->d_pull_cnt, 1)
     for (int i = 0; i < 2; ++i) { A(g.list_low[i], n) A(g.list_seg[i], (size_t)n + high_items) }
     for (int i = 0; i < 3; ++i) { A(g.fr_low[i], n) A(g.fr_seg[i], (size_t)n + high_items) }
     c->tally_slots = kSweepWaves;
@@ -689,7 +750,7 @@ int psn_upload_csr(psn_ctx *c, int32_t n, int64_t m2, const int64_t *row_off, co
         const long double bound = 8.0L * (long double)n * (long double)(h_chk[1] + 1) * (long double)(n + 1);
         if (bound > 4.0e18L) { free_graph_buffers(c); return fail(c, PSN_EOVERFLOW, "n^2 * max|cost| too large for int64 prices"); }
     }
-    scale_for_cover(c, (long long)c->h_flag[2]);
+    scale_for_cover(c, (long long)c->h_flag[2], (long long)c->h_flag[3]);
     const double tu4 = now_up();
     if ((rc = build_graph(c)) != PSN_OK) { free_graph_buffers(c); return rc; }
     if (dbg_up) fprintf(stderr, "psn_upload_csr: checks + rows %.1f copies + arc checks %.1f graph capture %.1f ms\n", tu3 - tu0, tu4 - tu3, now_up() - tu4);
@@ -835,7 +896,7 @@ int psn_build_network_rooms_device(psn_ctx *c, const psn_layout *lay, int32_t un
     if (e == hipSuccess && launch_cover(c) != PSN_OK) e = hipErrorUnknown;
     if (e == hipSuccess) e = hipStreamSynchronize(s);  // the host staging vectors die at return
     if (e != hipSuccess) { free_graph_buffers(c); return fail(c, PSN_EDEVICE, "psn_build_network_rooms_device", e); }
-    scale_for_cover(c, (long long)c->h_flag[2]);
+    scale_for_cover(c, (long long)c->h_flag[2], (long long)c->h_flag[3]);
     if ((rc = build_graph(c)) != PSN_OK) { free_graph_buffers(c); return rc; }
     if (ec_arc_base_out) std::copy(base.begin(), base.end(), ec_arc_base_out);
     c->uploaded = true;
@@ -1014,10 +1075,11 @@ int psn_patch_arcs(psn_ctx *c, int64_t count, const int64_t *arc_index, const in
         return fail(c, PSN_EINVAL, "patched arcs do not pair up; the network must be uploaded again");
     }
     c->cover_size = (long long)c->h_flag[2];
-    if (c->cover_size > c->cover_cap) {
+    c->noni_size = (long long)c->h_flag[3];
+    if (c->cover_size > c->cover_cap || c->noni_size > c->noni_cap) {
         // longer residual cycles are possible now: a larger cost scale, under which the kept prices mean
         // nothing, so the next solve starts cold; the replay graph carries the scale and is captured anew
-        scale_for_cover(c, c->cover_size);
+        scale_for_cover(c, c->cover_size, c->noni_size);
         c->solved = false;
         ++c->upload_gen;
         drop_group_cache(c);

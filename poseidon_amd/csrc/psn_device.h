@@ -27,7 +27,8 @@ constexpr int kClsLean = 4;      // cls[] bit: every step of the row is made of 
 constexpr int kClsSeg = 1;       // counter slot of the (vertex, segment) item lists (slot 0: lane list)
 constexpr int kHubPull = -2;     // hub_of[] value of a pull vertex (see DevGraph::pull_list); -1: an ordinary vertex
 constexpr int kMaxHubs = 128;    // highest-degree vertices whose atomics are pre-combined in LDS per workgroup
-constexpr double kTailFactor = 0.213, kTailPower = 0.65;  // Ctrl::tail_units = kTailFactor * (total supply)^kTailPower
+constexpr double kTailFactor = 0.1, kTailPower = 0.74;  // Ctrl::tail_units = kTailFactor * (total supply)^kTailPower
+constexpr int kDefaultRounds = 14;  // push/relabel rounds per replay, i.e. between two global updates
 constexpr int kDefaultAlphaLog2 = 4;  // epsilon / 16 per phase
 constexpr int kGuIters = 12;     // frontier expansions per replay (multiple of 3)
 constexpr int PSN_EINFEASIBLE_DEV = -4;

@@ -155,3 +155,70 @@ def test_tuned_baseline_variant_agrees_with_the_plain_oracle():
             assert capi.check(g, cap, price)[:2] == (0, tc)
             want = tc if want is None else want
             assert tc == want
+
+
+def _longest_simple_cycle(n, adj_pairs):
+    """Brute force: the largest number of arcs of a simple cycle in the undirected multigraph given
+    as a list of vertex pairs (a pair listed twice is two parallel arcs: a cycle of 2)."""
+    nbr = {v: {} for v in range(n)}
+    for u, v in adj_pairs:
+        nbr[u][v] = nbr[u].get(v, 0) + 1
+        nbr[v][u] = nbr[v].get(u, 0) + 1
+    best = 2 if any(c >= 2 for d in nbr.values() for c in d.values()) else 0
+
+    def walk(start, v, seen, length):
+        nonlocal best
+        for w in nbr[v]:
+            if w == start and length >= 2:
+                best = max(best, length + 1)
+            elif w > start and w not in seen:
+                seen.add(w)
+                walk(start, w, seen, length + 1)
+                seen.discard(w)
+
+    for s in range(n):
+        walk(s, s, {s}, 0)
+    return best
+
+
+def test_cycle_length_bound_holds_on_small_graphs():
+    """The cost scale rests on an upper bound for the number of arcs of a simple residual cycle:
+    min(n, 2 |cover|, 4 |cover minus its independent subset|).  Checked against the longest simple
+    cycle found by exhaustive search on small random graphs of several shapes (sparse, dense,
+    bipartite with hubs and leaves like a scheduling network, with parallel arcs)."""
+    rng = np.random.default_rng(5)
+    tight = 0
+    for trial in range(400):
+        n = int(rng.integers(2, 10))
+        kind = trial % 4
+        if kind == 0:
+            m = int(rng.integers(1, 3 * n))
+            tail, head = rng.integers(0, n, m), rng.integers(0, n, m)
+        elif kind == 1:
+            pairs = [(u, v) for u in range(n) for v in range(u + 1, n) if rng.random() < 0.7]
+            tail, head = np.array([p[0] for p in pairs], int), np.array([p[1] for p in pairs], int)
+        elif kind == 2:  # leaves -> hubs -> middle -> sink, the shape of a scheduling network
+            hubs = max(1, n // 4)
+            tail, head = [], []
+            for v in range(hubs + 1, n):
+                tail += [v, v]; head += [1 + int(rng.integers(0, hubs)), 0 if rng.random() < 0.5 else 1 + int(rng.integers(0, hubs))]
+            for h in range(1, hubs + 1):
+                tail.append(h); head.append(0)
+            tail, head = np.array(tail, int), np.array(head, int)
+        else:
+            m = int(rng.integers(1, 2 * n))
+            tail, head = rng.integers(0, n, m), rng.integers(0, n, m)
+            tail, head = np.concatenate([tail, tail[: m // 2]]), np.concatenate([head, head[: m // 2]])  # parallel arcs
+        keep = tail != head
+        tail, head = tail[keep], head[keep]
+        if tail.shape[0] == 0:
+            continue
+        m = tail.shape[0]
+        g = synth.graph_from_arcs(n, tail, head, np.ones(m, np.int64), np.ones(m, np.int64), np.zeros(n, np.int64))
+        bound = capi.cycle_bound(g)
+        longest = _longest_simple_cycle(n, list(zip(tail.tolist(), head.tolist())))
+        assert longest <= bound, (trial, n, tail.tolist(), head.tolist(), longest, bound)
+        tight += longest == bound
+    assert tight > 0  # the bound is attained on some of them
+    # the scheduling networks: classes and the sink are what is left outside the independent subset
+    assert capi.cycle_bound(synth.build_graph(synth.make_cluster(1, 1))) == 4 * 65
