@@ -9,7 +9,7 @@ an independent third-party solver that ships in this container: networkx 3.4.2
 absent from /root/reference), so these numbers pin the oracle against independent
 mathematics, not against the reference: parity with the reference stays unpinned.
 
-Run from the repo root:  python tests/golden/make_golden.py
+Run from the repo root:  python tests/golden/make_golden.py        (--all: with the slow parts below, about an hour)
 then, optionally (tens of minutes):  python tests/golden/make_golden.py --nx-c1-only
 which adds the networkx cost of config 1 / seed 1 to the existing file;
   python tests/golden/make_golden.py --ssp-c2
@@ -138,6 +138,10 @@ def main():
             out["entries"].append(e)
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
+    if "--all" in sys.argv:  # the slow parts as well: everything the committed file holds
+        patch_ssp_c2(path)
+        patch_nx_c1(path)
+        make_c4(os.path.join(os.path.dirname(path), "psn_c4_costs.json"))
 
 
 if __name__ == "__main__":

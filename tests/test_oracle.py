@@ -222,3 +222,14 @@ def test_cycle_length_bound_holds_on_small_graphs():
     assert tight > 0  # the bound is attained on some of them
     # the scheduling networks: classes and the sink are what is left outside the independent subset
     assert capi.cycle_bound(synth.build_graph(synth.make_cluster(1, 1))) == 4 * 65
+
+
+def test_every_golden_cost_rests_on_two_oracles_that_agree():
+    """Each committed optimum was found by the two C oracles independently (successive shortest
+    paths and cost scaling; at the 10 000-machine size the former takes seven minutes per network
+    and was run once, by tests/golden/make_golden.py --ssp-c2), and the small ones by networkx too."""
+    for e in _golden():
+        assert e["ssp"] == e["cost_scaling"] == e["optimal_cost"], (e["config"], e["seed"])
+        if e["config"] == 0:
+            assert e["networkx_network_simplex"] == e["optimal_cost"]
+    assert sorted((e["config"], e["seed"]) for e in _golden()) == [(c, s) for c in (0, 1, 2) for s in (1, 2, 3)]
