@@ -24,7 +24,20 @@ constexpr int kMaxVertices = 1 << 28;  // lane items pack the degree above bit 2
 constexpr int kClsLow = 0, kClsMed = 1, kClsHigh = 2;  // vertex classes by degree
 constexpr int kClsMask = 3;      // the class in a cls[] byte
 constexpr int kClsLean = 4;      // cls[] bit: every step of the row is made of aligned groups of 8 parallel arcs
-constexpr int kClsSeg = 1;       // counter slot of the (vertex, segment) item lists (slot 0: lane list)
+// Counters that many workgroups add to within one launch sit 128 bytes apart: atomics of the whole GPU
+// on one cache line are served one after the other (about 12 ns each, measured by
+// tools/ubench/atomic_contention.hip), whichever words of the line they name.
+// The two list sizes stay side by side: every sweep reads both when it starts, and a line more to wait for
+// costs each launch more than their appends cost each other.
+constexpr int kCntLine = 32;     // unsigned words per cache line
+constexpr int kSlotLow = 0, kSlotSeg = 1;                                // list counters: lane items, wave items
+constexpr int kSlotUnits = 1 * kCntLine, kSlotDeficits = 2 * kCntLine;  // work lists only: units of excess at the listed vertices (a vertex counts for at most 2^16 - 1); vertices that hold a deficit (hubs included)
+constexpr int kCntWords = 3 * kCntLine;  // words per counter block
+__host__ __device__ constexpr int cnt_slot(int j) { return j == 0 ? kSlotLow : (j == 1 ? kSlotSeg : (j == 2 ? kSlotUnits : kSlotDeficits)); }
+constexpr int kCntSlots = 4;
+constexpr int kHubShards = 16;   // copies of the per-hub accumulators the push sweep flushes into (workgroup b: copy b mod kHubShards)
+constexpr int kPurseStride = 16; // 64-bit words between the purses of two hubs (one cache line each)
+constexpr long long kHubShardsMinArcs = 2 << 20;  // residual arcs from which a network's hubs get purses and sharded accumulators
 constexpr int kHubPull = -2;     // hub_of[] value of a pull vertex (see DevGraph::pull_list); -1: an ordinary vertex
 constexpr int kMaxHubs = 128;    // highest-degree vertices whose atomics are pre-combined in LDS per workgroup
 constexpr double kTailFactor = 0.1, kTailPower = 0.74;  // Ctrl::tail_units = kTailFactor * (total supply)^kTailPower
@@ -48,9 +61,9 @@ struct Ctrl {
     int sat_on, gu_on, gu_init_on, rounds_on;
     int done, error;
     unsigned epoch, gu_stamp_base;
-    unsigned list_cnt[2][4];  // per list parity: lane items, wave items, units of excess at the listed vertices, vertices that hold a deficit
-    unsigned fr_cnt[3][4];
-    int gu_phase[2];  // global update, read by expansion k at [k & 1], written at [(k + 1) & 1]: 0 expanding, 1 the pull sweep just ran, 2 converged
+    alignas(128) unsigned list_cnt[2][kCntWords];  // per list parity, at kSlotLow / kSlotSeg / kSlotUnits / kSlotDeficits
+    alignas(128) unsigned fr_cnt[3][kCntLine];     // per frontier buffer, at kSlotLow / kSlotSeg
+    alignas(128) int gu_phase[2];  // global update, read by expansion k at [k & 1], written at [(k + 1) & 1]: 0 expanding, 1 the pull sweep just ran, 2 converged
     unsigned long long tally_refines, tally_gus;
     // Orientation (see Orient in the kernels): mirror = 1 while the sweeps work on the reversed
     // network; k_begin decides per replay, k_flip (flip_on) negates prices and excesses in place.
@@ -93,6 +106,17 @@ struct DevGraph {
     const int *hub_seg0;       // index of each hub's first segment
     i64 *seg_scan, *seg_add[2];
     int n_hub_segs;
+    // Hubs are neighbours in the vertex numbering (the task classes), so their excess[] and cand[] words
+    // share cache lines, and a line serves the atomics of the whole GPU one at a time.  During a push
+    // round a hub's words are therefore not touched: the waves that push from its segments draw on
+    // hub_purse[slot * kPurseStride] (the excess the hub held when the round's lists were built), and
+    // everything that is sent to the hub or taken from it is summed per workgroup and flushed to one of
+    // kHubShards copies [copy * kMaxHubs + slot] of a sum and a largest-key accumulator.  The relabel
+    // sweep that follows folds the copies into excess[] and cand[] and empties them.
+    // hub_shards = 0 (networks whose sweeps are a few hundred workgroups: the lines are not contended, and the
+    // fold would cost the relabel sweep more than it saves): none of this, the hubs' own words are used.
+    i64 *hub_purse, *hub_acc_add, *hub_acc_ext;
+    int hub_shards;  // kHubShards or 0
     i64 *dmax_part;  // largest distance handed out, one slot per wave of the largest sweep grid
     int *cap, *rcap;
     i64 *price, *excess, *cand, *dist;

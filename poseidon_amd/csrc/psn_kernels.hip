@@ -123,11 +123,13 @@ __device__ __forceinline__ int2 low_item(int v, unsigned r0, unsigned r1) { retu
 __device__ __forceinline__ int4 solo_item(int v, unsigned r0, unsigned r1, bool lean = false) { return make_int4(v, (int)r0, (int)r1, lean ? 3 : 1); }
 // A vertex larger than one item: its segments, starting at a per-round rotated one so that
 // vertices with common neighbours do not all begin at the same arcs.
-// flags >> 1 = 1 + index of the segment's bound slots when the vertex is a hub (seg1 = 1 + index
-// of its first segment), else 0.
+// Bits 1..23 of the flags = 1 + index of the segment's bound slots when the vertex is a hub (seg1 = 1 +
+// index of its first segment), else 0; bits 24..30 = the hub's slot (work lists of the push rounds only).
+constexpr int kItemHubShift = 24, kItemSegMask = (1 << 23) - 1;
+static_assert(kMaxHubs <= 128, "the hub slot takes 7 bits of an item's flags");
 __device__ __forceinline__ void append_split(unsigned *cnt, int4 *segl, int v, unsigned r0, unsigned r1, unsigned rot, int seg1 = 0) {
     const unsigned nseg = (r1 - r0 + kWSeg - 1) / kWSeg;
-    const unsigned base = aadd32(&cnt[kClsSeg], nseg);
+    const unsigned base = aadd32(&cnt[kSlotSeg], nseg);
     unsigned sg = rot % nseg;
     for (unsigned s = 0; s < nseg; ++s) {
         const unsigned a = r0 + sg * kWSeg;
@@ -195,7 +197,7 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
     if (threadIdx.x < 2) {
         for (int i = 0; i < kBlock / 64; ++i) my_tot += lds.sums[threadIdx.x][i];
         const unsigned want = my_tot + (threadIdx.x == 1 ? nsplit_segs + extra_segs : 0u);
-        if (want) my_base = aadd32(&cnt[threadIdx.x == 0 ? kClsLow : kClsSeg], want);
+        if (want) my_base = aadd32(&cnt[threadIdx.x == 0 ? kSlotLow : kSlotSeg], want);
     }
     if (nsplit && threadIdx.x < 64) {  // meanwhile: exclusive prefix of the staged vertices' segment counts
         unsigned run = 0;
@@ -253,9 +255,9 @@ __device__ __forceinline__ void block_append(unsigned *cnt, int2 *lowl, int4 *se
 // A few vertices (the sink, the task classes) receive most pushes and relaxations; their
 // same-address atomics would serialise at the memory side.  Each workgroup combines what
 // it sends to a hub in LDS and issues one global atomic per hub at the end of the kernel.
-struct HubAcc { i64 *add; i64 *ext; };  // LDS, kMaxHubs entries each: sum, and max (push) or min (distances)
+struct HubAcc { i64 *add; i64 *ext; i64 *out; };  // LDS, kMaxHubs entries each: sum received, and max (push) or min (distances); push rounds: sum drawn from the hub's purse
 __device__ __forceinline__ void hub_init(const HubAcc &hb, i64 ext_init) {
-    for (int i = threadIdx.x; i < kMaxHubs; i += kBlock) { hb.add[i] = 0; hb.ext[i] = ext_init; }
+    for (int i = threadIdx.x; i < kMaxHubs; i += kBlock) { hb.add[i] = 0; hb.ext[i] = ext_init; if (hb.out) hb.out[i] = 0; }
     __syncthreads();
 }
 __device__ __forceinline__ void lds_add(i64 *p, i64 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -271,13 +273,19 @@ static_assert(kMaxHubs <= kBlock, "one thread per hub slot");
 __device__ __forceinline__ int hub_vertex_of_thread(const DevGraph &g) {
     return (int)threadIdx.x < g.nhubs ? g.hub_vertex[threadIdx.x] : -1;
 }
-// end of a push/saturate kernel: one atomic per hub touched by this workgroup
+// end of a push/saturate kernel: one atomic per hub touched by this workgroup - on the hub's own words, or
+// (PUSH_ROUND on a network with hub_shards: a relabel sweep always follows and folds them) on this
+// workgroup's copy of the accumulators
+template <bool PUSH_ROUND>
 __device__ __forceinline__ void hub_flush_push(const DevGraph &g, const HubAcc &hb, int my_hub_vertex) {
     __syncthreads();
     if (my_hub_vertex >= 0) {
         const int i = threadIdx.x;
-        if (hb.add[i]) aadd64(&g.excess[my_hub_vertex], hb.add[i]);
-        if (hb.ext[i] > kNegInf) amax64(&g.cand[my_hub_vertex], hb.ext[i]);
+        const bool sharded = PUSH_ROUND && g.hub_shards != 0;
+        const int at = sharded ? (int)(blockIdx.x % (unsigned)kHubShards) * kMaxHubs + i : 0;
+        const i64 net = hb.add[i] - (PUSH_ROUND ? hb.out[i] : 0);
+        if (net) aadd64(sharded ? &g.hub_acc_add[at] : &g.excess[my_hub_vertex], net);
+        if (hb.ext[i] > kNegInf) amax64(sharded ? &g.hub_acc_ext[at] : &g.cand[my_hub_vertex], hb.ext[i]);
     }
 }
 
@@ -333,8 +341,6 @@ __device__ __forceinline__ void seg_note(const DevGraph &g, int hub, int r, i64 
     amax64(&g.seg_add[par][s], key);
 }
 
-constexpr int kCntUnits = 2;     // work-list counter slot: units of excess at the listed vertices (a vertex counts for at most 2^16 - 1)
-constexpr int kCntDeficits = 3;  // work-list counter slot: vertices that hold a deficit (hubs included)
 
 // ------------------------------------------------------------------- orientation
 // The sweeps can work on the network as it is or on its mirror image: every arc reversed, supplies
@@ -458,9 +464,12 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const Orient &o, 
     const int u = it.x;
     const unsigned r0 = (unsigned)it.y, r1 = (unsigned)it.z;
     constexpr bool solo = SOLO;
-    const int seg1 = SOLO ? 0 : it.w >> 1;  // 1 + index of this hub segment's bound slots, 0: none (a solo item has none)
+    const int seg1 = SOLO ? 0 : (it.w >> 1) & kItemSegMask;  // 1 + index of this hub segment's bound slots, 0: none (a solo item has none)
     const unsigned plane = (unsigned)(lane + rot) & 63u;
     const i64 pu = g.price[u];
+    // a hub's segment draws on the hub's purse and reports through the workgroup's accumulators (see DevGraph::hub_purse)
+    const int hu = seg1 && g.hub_shards ? it.w >> kItemHubShift : -1;  // the hub's slot rides in the item: no lookup before the purse can be asked
+    i64 *const purse = hu >= 0 ? &g.hub_purse[hu * kPurseStride] : &g.excess[u];
     int cp[9];
     if constexpr (SOLO) {
         // The only item of its vertex: listed because it holds excess, and nobody else takes excess
@@ -477,18 +486,18 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const Orient &o, 
         b = b > b0 ? b : b0;
         b = b > b1 ? b : b1;
         if (b <= pu) {
-            if (lane == 0 && b > kNegInf) amax64(&g.cand[u], b);
+            if (lane == 0 && b > kNegInf) { if (hu >= 0) lds_max(&hb.ext[hu], b); else amax64(&g.cand[u], b); }
             return;
         }
     }
-    i64 e0 = __hip_atomic_load(&g.excess[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    i64 e0 = __hip_atomic_load(purse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     e0 = __shfl(e0, 0);
     if (lane == 0) t.c[kTallyVisits]++;
     if (!SOLO && e0 <= 0) {  // drained by the vertex's other items: this one stays unscanned
-        if (lane == 0) amax64(&g.cand[u], kInf);
+        if (lane == 0) { if (hu >= 0) lds_max(&hb.ext[hu], kInf); else amax64(&g.cand[u], kInf); }
         return;
     }
-    i64 e = e0, best = kNegInf;
+    i64 e = e0, best = kNegInf, drawn = 0;
     bool incomplete = false;
     for (unsigned h = r0; h < r1; h += kStep) {
         const unsigned a0 = h + plane * 8, lim8 = min(r1, h + 512), at = h + 512 + plane, limt = min(r1, h + kStep);
@@ -547,11 +556,12 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const Orient &o, 
             } else {
                 granted = 0;
                 if (lane == 0) {
-                    const i64 old = aadd64(&g.excess[u], -total);
+                    const i64 old = aadd64(purse, -total);
                     granted = old <= 0 ? 0 : (old < total ? old : total);
-                    if (granted < total) aadd64(&g.excess[u], total - granted);
+                    if (granted < total) aadd64(purse, total - granted);
                 }
                 granted = __shfl(granted, 0);
+                drawn += granted;
             }
             i64 mine = granted - (incl - want);  // what this lane may push
             if (mine > 0) {
@@ -612,8 +622,9 @@ __device__ __forceinline__ void push_item_t(const DevGraph &g, const Orient &o, 
             g.seg_add[par ^ 1][seg1 - 1] = kNegInf;
         }
         if (incomplete) best = kInf;  // arcs not looked at: no relabel this round
-        if (best > kNegInf) amax64(&g.cand[u], best);
+        if (best > kNegInf) { if (hu >= 0) lds_max(&hb.ext[hu], best); else amax64(&g.cand[u], best); }
         if (solo && e != e0) aadd64(&g.excess[u], e - e0);
+        if (hu >= 0 && drawn) lds_add(&hb.out[hu], drawn);  // what left the purse leaves the hub's excess
     }
 }
 
@@ -626,21 +637,21 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
     Ctrl *ct = g.ctrl;
     const unsigned *cnt = ct->list_cnt[k & 1];
     const int on = ct->rounds_on;
-    const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg], epoch = ct->epoch;
+    const unsigned nlow = cnt[kSlotLow], nseg = cnt[kSlotSeg], epoch = ct->epoch;
     const int mirror = ct->mirror;
     CTRL_TOGETHER5(on, nlow, nseg, epoch, mirror);
     if (!on) return;
     const Orient o = orient_of(g, mirror);
-    if (blockIdx.x == 0 && threadIdx.x < 4) ct->list_cnt[(k + 1) & 1][threadIdx.x] = 0;
-    if (k == 0 && blockIdx.x == 0 && threadIdx.x == 0 && ct->first_units == ~0u) ct->first_units = cnt[kCntUnits];
+    if (blockIdx.x == 0 && threadIdx.x < kCntSlots) ct->list_cnt[(k + 1) & 1][cnt_slot((int)threadIdx.x)] = 0;
+    if (k == 0 && blockIdx.x == 0 && threadIdx.x == 0 && ct->first_units == ~0u) ct->first_units = cnt[kSlotUnits];
     if (nlow + nseg == 0) return;
     if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
         const unsigned i = aadd32(g.dbg_cnt, 1u);
         if (i < kDbgCap) g.dbg[i] = make_int4(1, k, (int)nlow, (int)nseg);
     }
-    __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
+    __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs], s_out[kMaxHubs];
     __shared__ int2 s_live[kBlock / 64][64];  // per wave: the residual arcs (index, capacity) of a sparse step
-    const HubAcc hb{s_add, s_max};
+    const HubAcc hb{s_add, s_max, s_out};
     hub_init(hb, kNegInf);
     const i64 S = o.S;
     const unsigned salt = epoch * 64u + (unsigned)k;
@@ -657,7 +668,7 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
         push_item(g, o, hb, s_live[threadIdx.x >> 6], it, S, mix32((unsigned)it.x, salt) >> 16, k & 1, t);
     }
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nlow; i += gridDim.x * kBlock) push_low(g, o, hb, lowl[i], S, k & 1, t);
-    hub_flush_push(g, hb, my_hub_vertex);
+    hub_flush_push<true>(g, hb, my_hub_vertex);
     if (blockIdx.x == 0 && threadIdx.x == 0) t.c[kTallyRounds]++;
     tally_flush<kTallyScans, kTallyPushes, kTallyVisits, kTallyRounds, kTallySkips>(g, t);
 }
@@ -670,27 +681,49 @@ __device__ __forceinline__ void push_body(const DevGraph &g, int k) {
 // The task classes sit next to each other, so the vertex sweep would hand all of them to one
 // workgroup, and one compute unit writes the ~4500 items of their segments several times
 // slower than the rest of the launch takes altogether.
-struct HubTurn { int v; bool act; unsigned r0, r1, nseg, first; int seg1; i64 e, c, p; };
-__device__ __forceinline__ HubTurn hub_fetch(const DevGraph &g, int hv) {
+struct HubTurn { int v; bool act; unsigned r0, r1, nseg, first; int seg1; i64 e, c, c_stored, p; };  // c: the candidate with the round's keys folded in; c_stored: what cand[] holds
+// The hub of slot `slot`: its words, with what the push round left in the accumulator copies folded in
+// (excess[] is brought up to date, the copies are emptied; the caller resets cand[]).
+struct HubShards { i64 add[kHubShards], ext[kHubShards]; };
+// (their addresses follow from the slot alone, so a sweep asks for them before it knows anything else)
+__device__ __forceinline__ void hub_shards_load(const DevGraph &g, int slot, bool have, HubShards &sh) {
+#pragma unroll
+    for (int k = 0; k < kHubShards; ++k) {
+        sh.add[k] = have ? g.hub_acc_add[k * kMaxHubs + slot] : 0;
+        sh.ext[k] = have ? g.hub_acc_ext[k * kMaxHubs + slot] : kNegInf;
+    }
+}
+__device__ __forceinline__ HubTurn hub_fetch(const DevGraph &g, int hv, int slot, const HubShards &sh) {
     HubTurn h;
-    h.v = hv; h.e = g.excess[hv]; h.c = g.cand[hv]; h.p = g.price[hv];
+    h.v = hv; h.e = g.excess[hv]; h.c = h.c_stored = g.cand[hv]; h.p = g.price[hv];
     h.r0 = g.row[hv]; h.r1 = g.row[hv + 1]; h.seg1 = g.seg1_of[hv];
+    const i64 (&add)[kHubShards] = sh.add, (&ext)[kHubShards] = sh.ext;
+    i64 sum = 0;
+#pragma unroll
+    for (int k = 0; k < kHubShards; ++k) {
+        sum += add[k];
+        h.c = ext[k] > h.c ? ext[k] : h.c;
+        if (add[k]) g.hub_acc_add[k * kMaxHubs + slot] = 0;
+        if (ext[k] > kNegInf) g.hub_acc_ext[k * kMaxHubs + slot] = kNegInf;
+    }
+    if (sum) { h.e += sum; g.excess[hv] = h.e; }
     return h;
 }
 __device__ __forceinline__ unsigned excess_units(i64 e) { return e > 0 ? (unsigned)(e < 65535 ? e : 65535) : 0u; }
 // The thread that looks after a hub relabels it and resets its candidate.
-__device__ __forceinline__ void hub_decide(const DevGraph &g, HubTurn &h, bool do_relabel, i64 eps, unsigned rot, Tally &t, unsigned *cnt) {
+__device__ __forceinline__ void hub_decide(const DevGraph &g, HubTurn &h, bool do_relabel, i64 eps, unsigned rot, Tally &t, unsigned &units, int slot) {
     h.act = h.e > 0;
     h.nseg = (h.r1 - h.r0 + kWSeg - 1) / kWSeg;
     h.first = (rot ^ (unsigned)h.v * 0x9E3779B9u) % h.nseg;
-    if (h.act) __hip_atomic_fetch_add(&cnt[kCntUnits], excess_units(h.e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (h.act) units += excess_units(h.e);
     if (h.act && do_relabel && h.c != kInf && h.c != kNegInf && h.c <= h.p) { g.price[h.v] = h.c - eps; t.c[kTallyRelabels]++; }
     const i64 nc = h.act ? kNegInf : kInf;
-    if (h.c != nc) g.cand[h.v] = nc;
+    if (h.c_stored != nc) g.cand[h.v] = nc;
+    if (g.hub_shards) g.hub_purse[slot * kPurseStride] = h.act ? h.e : 0;  // what the hub's segments may push in the coming round
 }
 // The hubs of a workgroup (hub slots blockIdx.x, blockIdx.x + gridDim.x, ...: one thread each) leave
 // their records in LDS; their segments take consecutive slots of the wave-item list.
-struct HubRec { int v, seg1; unsigned r0, r1, first, nseg, off; };  // nseg = 0: not active
+struct HubRec { int v, seg1, slot; unsigned r0, r1, first, nseg, off; };  // nseg = 0: not active
 struct HubLds { HubRec rec[kMaxHubs]; unsigned total, base; };
 __device__ __forceinline__ void append_hubs(const HubLds &hl, unsigned count, unsigned slot_base, int4 *segl) {
     const unsigned w = threadIdx.x >> 6, l = (unsigned)lane_id();
@@ -700,7 +733,7 @@ __device__ __forceinline__ void append_hubs(const HubLds &hl, unsigned count, un
             unsigned sg = h.first + i;  // rotated order, as append_split
             if (sg >= h.nseg) sg -= h.nseg;
             const unsigned a = h.r0 + sg * kWSeg;
-            segl[slot_base + h.off + i] = make_int4(h.v, (int)a, (int)min(h.r1, a + kWSeg), (h.seg1 + (int)sg) << 1);
+            segl[slot_base + h.off + i] = make_int4(h.v, (int)a, (int)min(h.r1, a + kWSeg), ((h.seg1 + (int)sg) << 1) | (h.slot << kItemHubShift));
         }
     }
 }
@@ -732,9 +765,11 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
     const int my_hs = (int)blockIdx.x + (int)threadIdx.x * (int)gridDim.x;
     const bool have_hub = threadIdx.x < (unsigned)kMaxHubs && my_hs < g.nhubs;
     const int hub_v = have_hub ? g.hub_vertex[my_hs] : -1;
+    HubShards hub_sh;
+    hub_shards_load(g, my_hs, have_hub && g.hub_shards != 0, hub_sh);
     const unsigned *cnt = ct->list_cnt[k & 1];
     const int on = ct->rounds_on;
-    const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg], epoch = ct->epoch;
+    const unsigned nlow = cnt[kSlotLow], nseg = cnt[kSlotSeg], epoch = ct->epoch;
     const i64 eps = ct->eps;
     CTRL_TOGETHER5(on, nlow, nseg, epoch, eps);
     if (!on) return;
@@ -742,18 +777,20 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
     if (do_relabel && nlow + nseg == 0) return;  // nothing was active
     const unsigned rot = mix32(epoch, (unsigned)k);
     Tally t;
+    unsigned units_acc = 0, ndef_acc = 0;  // this thread's share of the two totals, added up once per workgroup at the end
     __shared__ AppendLds s_app;
     __shared__ HubLds s_hub;
+    __shared__ unsigned s_tot[2][kBlock / 64];
     const unsigned n_my_hubs = (int)blockIdx.x < g.nhubs ? min((unsigned)kMaxHubs, ((unsigned)g.nhubs - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0u;
     if (n_my_hubs) {  // workgroup-uniform
         HubTurn hub{};
-        if (have_hub) hub = hub_fetch(g, hub_v);
+        if (have_hub) hub = hub_fetch(g, hub_v, my_hs, hub_sh);
         if (threadIdx.x == 0) s_hub.total = 0;
         __syncthreads();
         if (have_hub) {
-            hub_decide(g, hub, do_relabel, eps, rot, t, ct->list_cnt[dst]);
+            hub_decide(g, hub, do_relabel, eps, rot, t, units_acc, my_hs);
             HubRec r;
-            r.v = hub.v; r.seg1 = hub.seg1; r.r0 = hub.r0; r.r1 = hub.r1; r.first = hub.first;
+            r.v = hub.v; r.seg1 = hub.seg1; r.slot = my_hs; r.r0 = hub.r0; r.r1 = hub.r1; r.first = hub.first;
             r.nseg = hub.act ? hub.nseg : 0u;
             r.off = r.nseg ? __hip_atomic_fetch_add(&s_hub.total, r.nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
             s_hub.rec[threadIdx.x] = r;
@@ -777,24 +814,27 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
             const i64 nc = act[i] ? kNegInf : kInf;
             if (seg1[i] == 0 && c[i] != nc) g.cand[v[i]] = nc;
         }
-        {
-            unsigned units = 0, ndef = 0;
 #pragma unroll
-            for (int i = 0; i < kVpt; ++i) { units += act[i] ? excess_units(e[i]) : 0u; ndef += e[i] < 0; }  // e is 0 outside the vertex range
-            units = wave_sum_u32(units);
-            if (lane_id() == 0 && units) __hip_atomic_fetch_add(&ct->list_cnt[dst][kCntUnits], units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__ballot(ndef != 0)) {
-                ndef = wave_sum_u32(ndef);
-                if (lane_id() == 0) __hip_atomic_fetch_add(&ct->list_cnt[dst][kCntDeficits], ndef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        for (int i = 0; i < kVpt; ++i) { units_acc += act[i] ? excess_units(e[i]) : 0u; ndef_acc += e[i] < 0; }  // e is 0 outside the vertex range
         block_append<kVpt>(ct->list_cnt[dst], g.list_low[dst], g.list_seg[dst], act, v, cls, r0, r1, rot, s_app, hubs_pending ? hub_total : 0u, &hub_base);
         if (hubs_pending) { if (hub_total) append_hubs(s_hub, n_my_hubs, hub_base, g.list_seg[dst]); hubs_pending = false; }
     }
     if (hubs_pending && hub_total) {  // this workgroup had no vertices to sweep: the hubs' slots are taken on their own
-        if (threadIdx.x == 0) s_hub.base = aadd32(&ct->list_cnt[dst][kClsSeg], hub_total);
+        if (threadIdx.x == 0) s_hub.base = aadd32(&ct->list_cnt[dst][kSlotSeg], hub_total);
         __syncthreads();
         append_hubs(s_hub, n_my_hubs, s_hub.base, g.list_seg[dst]);
+    }
+    {
+        // one atomic per workgroup and total (a wave each would put thousands of them on one cache line)
+        units_acc = wave_sum_u32(units_acc);
+        ndef_acc = wave_sum_u32(ndef_acc);
+        if (lane_id() == 0) { s_tot[0][threadIdx.x >> 6] = units_acc; s_tot[1][threadIdx.x >> 6] = ndef_acc; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            unsigned x = 0;
+            for (int i = 0; i < kBlock / 64; ++i) x += s_tot[threadIdx.x][i];
+            if (x) __hip_atomic_fetch_add(&ct->list_cnt[dst][threadIdx.x == 0 ? kSlotUnits : kSlotDeficits], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     tally_flush<kTallyRelabels>(g, t);
 }
@@ -814,7 +854,7 @@ __device__ __forceinline__ void saturate_body(const DevGraph &g) {
     const i64 eps = ct->eps, S = o.S;
     Tally t;
     __shared__ i64 s_add[kMaxHubs], s_max[kMaxHubs];
-    const HubAcc hb{s_add, s_max};
+    const HubAcc hb{s_add, s_max, nullptr};
     hub_init(hb, kNegInf);
     const unsigned nquad = (g.m2 + 3) / 4;
     for (unsigned q = blockIdx.x * kBlock + threadIdx.x; q < nquad; q += gridDim.x * kBlock) {
@@ -858,7 +898,7 @@ __device__ __forceinline__ void saturate_body(const DevGraph &g) {
             }
         }
     }
-    hub_flush_push(g, hb, hub_vertex_of_thread(g));
+    hub_flush_push<false>(g, hb, hub_vertex_of_thread(g));
     tally_flush<kTallySat>(g, t);
 }
 
@@ -953,10 +993,10 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
     if (__ballot(nl != 0)) {
         const unsigned incl = wave_incl_scan_u32(nl);
         const unsigned tot = __shfl(incl, 63);
-        if (q.nlow + tot > kQCap) waveq_flush_one(q.low, q.nlow, &dcnt[kClsLow], dlow);
+        if (q.nlow + tot > kQCap) waveq_flush_one(q.low, q.nlow, &dcnt[kSlotLow], dlow);
         if (tot > kQCap) {  // more than the staging queue holds: straight to memory
             unsigned base = 0;
-            if (lane_id() == 0) base = aadd32(&dcnt[kClsLow], tot);
+            if (lane_id() == 0) base = aadd32(&dcnt[kSlotLow], tot);
             unsigned pos = __shfl(base, 0) + incl - nl;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) if (cls[j] == kClsLow) dlow[pos++] = low_item(hd[j], r0[j], r1[j]);
@@ -970,10 +1010,10 @@ __device__ __forceinline__ void gu_commit_batch(const DevGraph &g, WaveQ &q, uns
     if (__ballot(ns != 0)) {
         const unsigned incl = wave_incl_scan_u32(ns);
         const unsigned tot = __shfl(incl, 63);
-        if (q.nseg + tot > kQCap) waveq_flush_one(q.seg, q.nseg, &dcnt[kClsSeg], dseg);
+        if (q.nseg + tot > kQCap) waveq_flush_one(q.seg, q.nseg, &dcnt[kSlotSeg], dseg);
         if (tot > kQCap) {
             unsigned base = 0;
-            if (lane_id() == 0) base = aadd32(&dcnt[kClsSeg], tot);
+            if (lane_id() == 0) base = aadd32(&dcnt[kSlotSeg], tot);
             unsigned pos = __shfl(base, 0) + incl - ns;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) if (cls[j] == kClsMed) dseg[pos++] = solo_item(hd[j], r0[j], r1[j], (clsb[j] & kClsLean) != 0);
@@ -993,7 +1033,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     const int src = k % 3, dst = (k + 1) % 3, clr = (k + 2) % 3;
     const unsigned *cnt = ct->fr_cnt[src];
     const int on = ct->gu_on;
-    const unsigned nlow = cnt[kClsLow], nseg = cnt[kClsSeg];
+    const unsigned nlow = cnt[kSlotLow], nseg = cnt[kSlotSeg];
     const int phase = ct->gu_phase[k & 1];
     const unsigned npull = *g.pull_cnt;
     const int sh = ct->eps_shift;
@@ -1003,7 +1043,7 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     CTRL_TOGETHER4(mirror, on, nlow, nseg);
     if (!on) return;
     const Orient o = orient_of(g, mirror);
-    if (blockIdx.x == 0 && threadIdx.x < 4) ct->fr_cnt[clr][threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 2) ct->fr_cnt[clr][threadIdx.x] = 0;
     // What this launch does follows from words it does not write: the frontier it reads and the
     // phase the launch before it left.  A dry frontier is followed by one sweep over the pull
     // vertices; if that queues nothing either, the update has converged.
@@ -1265,8 +1305,8 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
     const i64 hub_seen = hub_cand ? __hip_atomic_load(&g.dist[my_hub_vertex], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the staged queue entries are in LDS
     unsigned base_low = 0, base_seg = 0;
-    if (lane == 0 && q.nlow) base_low = aadd32(&dcnt[kClsLow], q.nlow);
-    if (lane == 0 && q.nseg) base_seg = aadd32(&dcnt[kClsSeg], q.nseg);
+    if (lane == 0 && q.nlow) base_low = aadd32(&dcnt[kSlotLow], q.nlow);
+    if (lane == 0 && q.nseg) base_seg = aadd32(&dcnt[kSlotSeg], q.nseg);
     i64 *dmax_slot = g.dmax_part + wave;
     unsigned long long *tslot = g.tally + (size_t)wave * kTallyN;  // this wave's work counters
     i64 dmax_seen = 0;
@@ -1340,7 +1380,7 @@ __device__ __forceinline__ void gu_apply_body(const DevGraph &g, int n_iters) {
     if (ct->gu_on) {
         const unsigned *c = ct->fr_cnt[n_iters % 3];
         const int phase = ct->gu_phase[n_iters & 1];
-        const bool dry = c[kClsLow] + c[kClsSeg] == 0;
+        const bool dry = c[kSlotLow] + c[kSlotSeg] == 0;
         // converged: seen by an expansion already, or the last one was a pull sweep that queued
         // nothing (or found the frontier dry with no pull vertices to ask)
         if (phase == 2 || (dry && (phase == 1 || *g.pull_cnt == 0))) apply = true;
@@ -1352,7 +1392,7 @@ __device__ __forceinline__ void gu_apply_body(const DevGraph &g, int n_iters) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (apply || give_up) { ct->gu_active = 0; ct->need_gu = 0; }
         if (rounds) ct->rounds_on = 1;
-        for (int j = 0; j < 4; ++j) ct->list_cnt[0][j] = 0;
+        for (int j = 0; j < kCntSlots; ++j) ct->list_cnt[0][cnt_slot(j)] = 0;
     }
     if (!apply) return;
     const i64 eps = ct->eps;
@@ -1383,13 +1423,13 @@ __device__ __forceinline__ void gu_apply_body(const DevGraph &g, int n_iters) {
 __device__ __forceinline__ bool rounds_closed_solve(const Ctrl *ct, int n_rounds) {
     if (ct->done || ct->error || !ct->rounds_on) return false;
     const unsigned *c = ct->list_cnt[n_rounds & 1];
-    return c[kClsLow] + c[kClsSeg] == 0 && ct->eps_shift == 0;
+    return c[kSlotLow] + c[kSlotSeg] == 0 && ct->eps_shift == 0;
 }
 __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
     Ctrl *ct = g.ctrl;
     if (!ct->done && !ct->error && ct->rounds_on) {  // close the rounds of the previous replay
         const unsigned *c = ct->list_cnt[n_rounds & 1];
-        const unsigned left = c[kClsLow] + c[kClsSeg];
+        const unsigned left = c[kSlotLow] + c[kSlotSeg];
         // A phase other than the last one need not route its last units of excess: they join what
         // the next phase's saturation sets free (every phase starts by restoring its own
         // epsilon-optimality, whatever pseudoflow it is given).  The long tail of a phase - a
@@ -1397,7 +1437,7 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
         // phase, instead of once per phase.  What is left is measured in units of excess at the
         // active vertices, not in work items: a few large vertices that still hold thousands of
         // units (an over-subscribed cluster) are not a tail.
-        if (left == 0 || (ct->eps_shift > 0 && c[kCntUnits] <= (unsigned)ct->tail_units)) {
+        if (left == 0 || (ct->eps_shift > 0 && c[kSlotUnits] <= (unsigned)ct->tail_units)) {
             if (ct->eps_shift == 0) {
                 ct->done = 1;
             } else {
@@ -1431,7 +1471,7 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
             want = 0;
         } else if (ct->need_gu && !ct->gu_active && ct->eps_shift <= ct->mirror_max_shift && ct->mirror_ratio > 0) {
             const unsigned *c = ct->list_cnt[n_rounds & 1];
-            const unsigned long long items = (unsigned long long)c[kClsLow] + c[kClsSeg], ndef = c[kCntDeficits];
+            const unsigned long long items = (unsigned long long)c[kSlotLow] + c[kSlotSeg], ndef = c[kSlotDeficits];
             if (ndef > 0 && ndef * (unsigned long long)ct->mirror_ratio <= items * 4ull) want = !ct->mirror;
         }
         if (want != ct->mirror) { ct->mirror = want; ct->flip_on = 1; }
@@ -1443,7 +1483,7 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
             ct->gu_active = 1;
             ct->gu_init_on = 1;
             ct->tally_gus++;
-            for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) ct->fr_cnt[i][j] = 0;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) ct->fr_cnt[i][j] = 0;
             ct->gu_phase[0] = ct->gu_phase[1] = 0;
             ct->gu_stamp_base = 0;
         } else {
@@ -1481,6 +1521,7 @@ __device__ __forceinline__ void reset_body(const DevGraph &g, const i64 *supply,
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n_hub_segs; i += gridDim.x * kBlock) {
         g.seg_scan[i] = kInf; g.seg_add[0][i] = kNegInf; g.seg_add[1][i] = kNegInf;
     }
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < kHubShards * kMaxHubs; i += gridDim.x * kBlock) { g.hub_acc_add[i] = 0; g.hub_acc_ext[i] = kNegInf; }
     if (zero_tally)
         for (int i = blockIdx.x * kBlock + threadIdx.x; i < kSweepWaves * kTallyN; i += gridDim.x * kBlock) g.tally[i] = 0;
 }
