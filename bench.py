@@ -125,7 +125,7 @@ def service_rounds(config_id, seed, device, churn_rounds=2):
              "warm": int(st.last_round_warm), "deltas": n_deltas, "cost": int(st.total_cost),
              "patched_arcs": int(st.patched_arcs), "cap_updates": int(st.cap_updates), "supply_updates": int(st.supply_updates),
              # why a warm solve costs what it does: the epsilon its first phase ran at, the units of excess on the
-             # work list when its first round started, and the replays (one global update + 12 rounds each) it took
+             # work list when its first round started, and the replays (one global update + 14 rounds each) it took
              "solve": {"device_ms": round(st.solve_device_ms, 2), "first_eps_log2": int(st.solve_first_eps_log2), "first_units": int(st.solve_first_units),
                        "phases": int(st.solve_refines), "replays": int(st.solve_replays), "last_phase_replays": int(st.solve_last_phase_replays),
                        "rounds": int(st.solve_rounds), "global_updates": int(st.solve_global_updates), "pushes": int(st.solve_pushes)}}
@@ -203,7 +203,7 @@ def service_rounds(config_id, seed, device, churn_rounds=2):
     out["cold_solve_of_last_churned_cluster"] = {"device_ms": round(rc.solve_ms, 2), "first_eps_log2": rc.first_eps_log2, "first_units": rc.first_units,
                                                   "phases": rc.refines, "replays": rc.replays, "last_phase_replays": rc.last_phase_replays,
                                                   "rounds": rc.rounds, "global_updates": rc.global_updates, "pushes": rc.pushes}
-    out["why_warm_is_not_cheaper"] = ("a solve is its replays (a global update over the whole network + 12 rounds, about half a millisecond at "
+    out["why_warm_is_not_cheaper"] = ("a solve is its replays (a global update over the whole network + 14 rounds, about half a millisecond at "
                                       "10 000 machines); re-priced machines with free slots are genuinely cheaper or dearer by hundreds of cost "
                                       "units, so the kept prices are violated by that much, the scaling resumes near the epsilon a cold solve "
                                       "starts at and runs the same phases; it moves a third of the pushes in as many replays.  With only pods "

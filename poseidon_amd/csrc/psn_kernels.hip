@@ -1427,9 +1427,12 @@ __device__ __forceinline__ bool rounds_closed_solve(const Ctrl *ct, int n_rounds
 }
 __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
     Ctrl *ct = g.ctrl;
+    // what the last relabel sweep counted sits on three cache lines: asked for together, ahead of the branches that use it
+    const unsigned *const c = ct->list_cnt[n_rounds & 1];
+    const unsigned c_low = c[kSlotLow], c_seg = c[kSlotSeg], c_units = c[kSlotUnits], c_ndef = c[kSlotDeficits];
+    CTRL_TOGETHER4(c_low, c_seg, c_units, c_ndef);
     if (!ct->done && !ct->error && ct->rounds_on) {  // close the rounds of the previous replay
-        const unsigned *c = ct->list_cnt[n_rounds & 1];
-        const unsigned left = c[kSlotLow] + c[kSlotSeg];
+        const unsigned left = c_low + c_seg;
         // A phase other than the last one need not route its last units of excess: they join what
         // the next phase's saturation sets free (every phase starts by restoring its own
         // epsilon-optimality, whatever pseudoflow it is given).  The long tail of a phase - a
@@ -1437,7 +1440,7 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
         // phase, instead of once per phase.  What is left is measured in units of excess at the
         // active vertices, not in work items: a few large vertices that still hold thousands of
         // units (an over-subscribed cluster) are not a tail.
-        if (left == 0 || (ct->eps_shift > 0 && c[kSlotUnits] <= (unsigned)ct->tail_units)) {
+        if (left == 0 || (ct->eps_shift > 0 && c_units <= (unsigned)ct->tail_units)) {
             if (ct->eps_shift == 0) {
                 ct->done = 1;
             } else {
@@ -1470,8 +1473,7 @@ __device__ __forceinline__ void begin_body(const DevGraph &g, int n_rounds) {
         if (ct->need_sat) {
             want = 0;
         } else if (ct->need_gu && !ct->gu_active && ct->eps_shift <= ct->mirror_max_shift && ct->mirror_ratio > 0) {
-            const unsigned *c = ct->list_cnt[n_rounds & 1];
-            const unsigned long long items = (unsigned long long)c[kSlotLow] + c[kSlotSeg], ndef = c[kSlotDeficits];
+            const unsigned long long items = (unsigned long long)c_low + c_seg, ndef = c_ndef;
             if (ndef > 0 && ndef * (unsigned long long)ct->mirror_ratio <= items * 4ull) want = !ct->mirror;
         }
         if (want != ct->mirror) { ct->mirror = want; ct->flip_on = 1; }

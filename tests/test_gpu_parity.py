@@ -512,6 +512,50 @@ def test_leaf_vertices_that_fetch_their_own_distance(solver):
         assert tc == r.total_cost, (trial, tc, r.total_cost)
 
 
+@pytest.mark.parametrize("shards", ["1", "0"])
+def test_hub_purses_and_sharded_accumulators_on_and_off(monkeypatch, shards):
+    """Networks from two million residual arcs keep their hubs' excess in per-hub purses during a push
+    round and collect what the hubs receive in sharded accumulators that the relabel sweep folds back;
+    smaller networks use the hubs' own words.  Both ways forced on networks of either kind: star-like
+    random graphs whose hubs are sources, sinks and pass-through vertices (with replays on the reversed
+    network forced, which turns every sink into a source), the 1 000-machine cluster, and - the other
+    way round from its default - the full-size network; optimum and certificate as everywhere."""
+    monkeypatch.setenv("PSN_HUB_SHARDS", shards)
+    monkeypatch.setenv("PSN_MIRROR_DELTA", "40")
+    rng = np.random.default_rng(321)
+    with pa.Solver(device=0) as s:
+        for trial in range(6):
+            n = 500
+            hubs = rng.integers(0, n, 4)
+            m = 12000
+            tail = np.where(rng.random(m) < 0.45, hubs[rng.integers(0, 4, m)], rng.integers(0, n, m))
+            head = np.where(rng.random(m) < 0.45, hubs[rng.integers(0, 4, m)], rng.integers(0, n, m))
+            keep = tail != head
+            tail, head = tail[keep], head[keep]
+            cap = rng.integers(1, int(rng.choice([2, 30, 1000])), tail.shape[0])
+            cost = rng.integers(0, int(rng.choice([4, 5000])), tail.shape[0])
+            f = rng.integers(0, cap + 1)
+            supply = np.zeros(n, np.int64)
+            np.add.at(supply, tail, f)
+            np.add.at(supply, head, -f)
+            g = synth.graph_from_arcs(n, tail, head, cap, cost, supply)
+            assert (np.diff(g.row_off) > 1152).any()
+            r = solve_and_certify(s, g)
+            rc, tc, _, _, _ = capi.cost_scaling(g)
+            assert rc == 0 and tc == r.total_cost, (trial, tc, r.total_cost)
+            r2 = s.solve(warm_start=True)
+            assert r2.total_cost == tc and r2.pushes == 0
+        for cfg, seed in ((1, 2), (2, 2)) if shards == "0" else ((1, 2),):
+            cl = pa.synth_cluster(cfg, seed)
+            net = pa.build_network(cl)
+            s.upload(net)
+            s.eval_costs(cl, net)
+            r = s.solve()
+            assert r.total_cost == _gold(cfg, seed)["optimal_cost"]
+            og = synth.build_graph(synth.make_cluster(cfg, seed))
+            assert capi.check(og, s.residual(), s.prices(), scale=s.price_scale())[:2] == (0, r.total_cost)
+
+
 @pytest.mark.parametrize("ratio", ["1", "3", "12"])
 def test_replays_on_the_reversed_network_end_at_the_same_optimum(solver, monkeypatch, ratio):
     """Replays may work on the mirror image of the network (arcs reversed, supplies and prices
