@@ -122,7 +122,7 @@ def service_rounds(config_id, seed, device, churn_rounds=2):
     def part(st, wall_ms, n_deltas, moved=None):
         d = {"round_ms": round(st.total_ms, 2), "wall_ms": round(wall_ms, 2), "build_ms": round(st.build_ms, 2), "upload_ms": round(st.upload_ms, 2),
              "update_ms": round(st.update_ms, 2), "solve_ms": round(st.solve_ms, 2), "extract_ms": round(st.extract_ms, 2),
-             "warm": int(st.last_round_warm), "deltas": n_deltas, "cost": int(st.total_cost),
+             "warm": int(st.last_round_warm), "warm_declined": int(st.solve_warm_declined), "deltas": n_deltas, "cost": int(st.total_cost),
              "patched_arcs": int(st.patched_arcs), "cap_updates": int(st.cap_updates), "supply_updates": int(st.supply_updates),
              # why a warm solve costs what it does: the epsilon its first phase ran at, the units of excess on the
              # work list when its first round started, and the replays (one global update + 14 rounds each) it took
@@ -198,16 +198,21 @@ def service_rounds(config_id, seed, device, churn_rounds=2):
     out["cold_solve_of_last_churned_cluster_ms"] = round(rc.solve_ms, 2)
     out["warm_equals_cold_cost"] = bool(rc.total_cost == rounds[-1][1]["cost"])
     out["allocations_during_warm_rounds"] = int(allocs_warm)
+    # churn rounds (applied in place; "warm" says whether the solver resumed from the kept state or declined it) against
+    # the cold solve of the same cluster
     warm_ms = float(np.mean([p["solve"]["device_ms"] for name, p in rounds[1:1 + churn_rounds]]))
     out["warm_over_cold_solve"] = round(warm_ms / max(rc.solve_ms, 1e-9), 3)
+    out["churn_rounds_that_declined_the_kept_state"] = int(sum(p["warm_declined"] for name, p in rounds[1:1 + churn_rounds]))
     out["cold_solve_of_last_churned_cluster"] = {"device_ms": round(rc.solve_ms, 2), "first_eps_log2": rc.first_eps_log2, "first_units": rc.first_units,
                                                   "phases": rc.refines, "replays": rc.replays, "last_phase_replays": rc.last_phase_replays,
                                                   "rounds": rc.rounds, "global_updates": rc.global_updates, "pushes": rc.pushes}
     out["why_warm_is_not_cheaper"] = ("a solve is its replays (a global update over the whole network + 14 rounds, about half a millisecond at "
                                       "10 000 machines); re-priced machines with free slots are genuinely cheaper or dearer by hundreds of cost "
                                       "units, so the kept prices are violated by that much, the scaling resumes near the epsilon a cold solve "
-                                      "starts at and runs the same phases; it moves a third of the pushes in as many replays.  With only pods "
-                                      "replaced (churn_pods_only) no cost moves and the first epsilon is small")
+                                      "starts at and runs the same phases; it moves a third of the pushes in as many replays or more.  A kept "
+                                      "state whose first epsilon is within a power of two of a cold solve's is therefore declined and the "
+                                      "round solved cold on the resident network (warm_declined).  With only pods replaced (churn_pods_only) "
+                                      "no cost moves and the first epsilon is small")
     return out, (cl2, out_mask)
 
 

@@ -91,9 +91,14 @@ typedef struct psn_result {
                               * i.e. what the first phase's saturation (plus, warm, the changes since the last solve) set free */
     int32_t first_eps_log2;  /* log2 of the epsilon the first phase ran at (scaled costs) */
     int32_t last_phase_replays; /* replays spent at epsilon = 1 */
+    int32_t warm_declined;   /* 1: PSN_WARM_START was asked for and the kept state was there, but it is violated by about as
+                              * much as an empty one (its first epsilon within a power of two of a cold solve's), so the
+                              * solve started cold (warm_started = 0) */
+    int32_t reserved_;
 } psn_result;
 
-#define PSN_WARM_START 1u    /* psn_solve: keep prices and flow from the previous solve */
+#define PSN_WARM_START 1u    /* psn_solve: keep prices and flow from the previous solve (psn_solve declines a kept state that is no
+                              * head start and says so in psn_result::warm_declined; psn_solve_batch resumes whenever asked) */
 
 /* Shape of a psn flow network (vertex id ranges), needed by cost evaluation and
  * placement extraction.  Vertex ids: 0 sink | 1..N machines | N+1..N+E task

@@ -117,6 +117,7 @@ typedef struct psn_svc_stats {
     int64_t solve_replays, solve_last_phase_replays, solve_refines, solve_rounds, solve_global_updates, solve_pushes,
         solve_first_units, solve_first_eps_log2;
     double solve_device_ms;
+    int64_t solve_warm_declined;  /* 1: the round was applied in place and offered its kept state, the solver started cold (psn_result::warm_declined) */
 } psn_svc_stats;
 
 int psn_svc_create(const psn_svc_config *cfg, psn_svc **out);

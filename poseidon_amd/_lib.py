@@ -59,7 +59,8 @@ class Result(C.Structure):
                 ("gu_iterations", C.c_uint64), ("global_updates", C.c_uint64), ("launches", C.c_uint64),
                 ("solve_ms", C.c_double), ("gu_arc_skips", C.c_uint64), ("arc_skips", C.c_uint64),
                 ("warm_started", C.c_int32), ("mirrored_replays", C.c_int32), ("replays", C.c_uint64),
-                ("first_units", C.c_uint64), ("first_eps_log2", C.c_int32), ("last_phase_replays", C.c_int32)]
+                ("first_units", C.c_uint64), ("first_eps_log2", C.c_int32), ("last_phase_replays", C.c_int32),
+                ("warm_declined", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Layout(C.Structure):

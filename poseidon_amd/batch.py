@@ -78,4 +78,4 @@ def solve_batch(solvers, warm_start: bool = False, workers: int = 0):
     if rc != _lib.PSN_OK:
         bad = next((s for s, r in zip(solvers, out) if r.status != _lib.PSN_OK), solvers[0] if solvers else None)
         _lib.check(rc, bad._ctx if bad is not None else None)
-    return [SolveResult(*(getattr(r, f[0]) for f in _lib.Result._fields_)) for r in out]
+    return [SolveResult(*(getattr(r, f[0]) for f in _lib.Result._fields_ if not f[0].startswith("reserved"))) for r in out]

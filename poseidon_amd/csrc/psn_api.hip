@@ -1209,11 +1209,37 @@ static int solve_prepare(psn_ctx *c, hipStream_t s, bool warm, i64 *h_scalar) {
     HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, kScalarSlots * sizeof(i64), s));
     HIPCHK(c, hipMemsetAsync(g.tally, 0, (size_t)c->tally_slots * kTallyN * sizeof(unsigned long long), s));
     if (g.dbg_cnt) HIPCHK(c, hipMemsetAsync(g.dbg_cnt, 0, sizeof(unsigned), s));
-    if (!warm) hipLaunchKernelGGL(k_cost_stats, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 2);
+    hipLaunchKernelGGL(k_cost_stats, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 2);  // (a warm solve compares its first epsilon with a cold one's)
     if (warm) hipLaunchKernelGGL(k_max_violation, dim3(kGrid), dim3(kBlock), 0, s, g, c->d_scalar + 1);
     hipLaunchKernelGGL(k_sum_supply, dim3(std::max(1, std::min(64, (g.n + kBlock - 1) / kBlock))), dim3(kBlock), 0, s, c->d_supply, g.n, c->d_scalar + kSupplySumSlot, c->d_scalar + kSourcesSlot, c->d_scalar + kSupplyUnitsSlot);
     HIPCHK(c, hipMemcpyAsync(h_scalar, c->d_scalar, kScalarSlots * sizeof(i64), hipMemcpyDeviceToHost, s));
     return PSN_OK;
+}
+// log2 of the epsilon the first phase of a cold solve runs at.
+// Zero flow with zero prices is 0-optimal when no usable arc has a negative cost, so the
+// first phase may start anywhere; starting at the 90th-percentile cost bucket instead of
+// the largest cost skips the phases in which only a few expensive arcs (the unscheduled
+// penalty) are distinguishable.  Any starting epsilon is correct: every phase first
+// saturates the arcs that violate its epsilon.
+static int cold_first_shift(const psn_ctx *c, const i64 *h_scalar, int alpha_log2) {
+    i64 c0 = std::max<i64>(1, h_scalar[2]);
+    if (h_scalar[3] == 0 && !(c->cfg.flags & PSN_CFG_EPS_FROM_MAX)) {
+        i64 total = 0, run = 0;
+        for (int b = 0; b < 32; ++b) total += h_scalar[4 + b];
+        for (int b = 0; b < 32; ++b) {
+            run += h_scalar[4 + b];
+            if (run * 10 >= total * 9) { c0 = std::min<i64>(c0, (i64)1 << b); break; }
+        }
+    }
+    return std::max(0, ceil_log2(c0 * c->g.scale) - alpha_log2);
+}
+// ... and of a warm one: the kept pseudoflow is v-optimal for v = largest violation; resume one step below it.
+static int warm_first_shift(const i64 *h_scalar, int alpha_log2) {
+    return h_scalar[1] > 1 ? std::max(0, ceil_log2(h_scalar[1]) - alpha_log2) : 0;
+}
+static int warm_alpha_log2(const psn_ctx *c) {
+    if (const char *ev = std::getenv("PSN_WARM_ALPHA_LOG2")) return std::max(1, std::min(12, atoi(ev)));
+    return c->cfg.alpha_log2;
 }
 // The control block a solve starts from (into the context's pinned copy) and its upload.
 static Ctrl solve_init(psn_ctx *c, bool warm, const i64 *h_scalar) {
@@ -1237,27 +1263,11 @@ static Ctrl solve_init(psn_ctx *c, bool warm, const i64 *h_scalar) {
     }
     int shift0;
     if (!warm) {
-        // Zero flow with zero prices is 0-optimal when no usable arc has a negative cost, so the
-        // first phase may start anywhere; starting at the 90th-percentile cost bucket instead of
-        // the largest cost skips the phases in which only a few expensive arcs (the unscheduled
-        // penalty) are distinguishable.  Any starting epsilon is correct: every phase first
-        // saturates the arcs that violate its epsilon.
-        i64 c0 = std::max<i64>(1, h_scalar[2]);
-        if (h_scalar[3] == 0 && !(c->cfg.flags & PSN_CFG_EPS_FROM_MAX)) {
-            i64 total = 0, run = 0;
-            for (int b = 0; b < 32; ++b) total += h_scalar[4 + b];
-            for (int b = 0; b < 32; ++b) {
-                run += h_scalar[4 + b];
-                if (run * 10 >= total * 9) { c0 = std::min<i64>(c0, (i64)1 << b); break; }
-            }
-        }
-        shift0 = ceil_log2(c0 * g.scale) - init.alpha_log2;
+        shift0 = cold_first_shift(c, h_scalar, init.alpha_log2);
     } else {
-        // the kept pseudoflow is v-optimal for v = largest violation: resume one step below it
-        if (const char *ev = std::getenv("PSN_WARM_ALPHA_LOG2")) init.alpha_log2 = std::max(1, std::min(12, atoi(ev)));
-        shift0 = h_scalar[1] > 1 ? ceil_log2(h_scalar[1]) - init.alpha_log2 : 0;
+        init.alpha_log2 = warm_alpha_log2(c);
+        shift0 = warm_first_shift(h_scalar, init.alpha_log2);
     }
-    if (shift0 < 0) shift0 = 0;
     init.eps_shift = shift0;
     init.eps = (i64)1 << shift0;
     init.need_sat = 1;
@@ -1321,7 +1331,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     if (!c || !out) return fail(c, PSN_EINVAL, "null argument");
     std::memset(out, 0, sizeof(*out));
     if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
-    const bool warm = (flags & PSN_WARM_START) && c->solved;
+    bool warm = (flags & PSN_WARM_START) && c->solved;
     HIPCHK(c, hipSetDevice(c->device));
     for (int i = 0; i < PSN_KT_CLASSES; ++i) { c->kt_ms[i] = 0; c->kt_calls[i] = 0; }
     hipStream_t s = c->stream;
@@ -1331,6 +1341,21 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     int rc = solve_prepare(c, s, warm, h_scalar);
     if (rc != PSN_OK) return rc;
     HIPCHK(c, hipStreamSynchronize(s));
+    bool declined = false;
+    if (warm) {
+        // A kept state that is violated by nearly as much as zero flow with zero prices is no head start: the
+        // scaling runs the same phases from it and, measured on re-priced 10 000-machine clusters, more
+        // replays (37-44 against 33).  Within kWarmDeclineSteps powers of two of a cold solve's first epsilon
+        // the solve starts cold instead; the result says so.
+        int steps = kWarmDeclineSteps;
+        if (const char *ev = std::getenv("PSN_WARM_DECLINE")) steps = atoi(ev);  // development: -1 never declines
+        if (steps >= 0 && warm_first_shift(h_scalar, warm_alpha_log2(c)) + steps >= cold_first_shift(c, h_scalar, c->cfg.alpha_log2)) {
+            warm = false;
+            declined = true;
+            if ((rc = solve_prepare(c, s, false, h_scalar)) != PSN_OK) return rc;
+            HIPCHK(c, hipStreamSynchronize(s));
+        }
+    }
     if ((rc = solve_start(c, s, warm, h_scalar)) != PSN_OK) return rc;
     const int first_shift = c->h_ctrl->eps_shift;
     // ---- replay until done
@@ -1406,6 +1431,7 @@ int psn_solve(psn_ctx *c, uint32_t flags, psn_result *out) {
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     solve_report(c, out, status, h_cost, h_tally, replays, c->launches_per_replay, ms, warm, first_shift);
+    out->warm_declined = declined ? 1 : 0;
     if (std::getenv("PSN_DEBUG_SOLVE"))
         fprintf(stderr, "psn_solve: %s first shift %d (max violation %lld) refines %d replays %lld rounds %llu gus %llu gu_iters %llu pushes %llu relabels %llu %.2f ms\n",
                 warm ? "warm" : "cold", ceil_log2(std::max<i64>(1, warm ? h_scalar[1] : h_scalar[2] * g.scale)) - c->cfg.alpha_log2, (long long)h_scalar[1], out->refines, replays,

@@ -43,6 +43,7 @@ constexpr int kMaxHubs = 128;    // highest-degree vertices whose atomics are pr
 constexpr double kTailFactor = 0.1, kTailPower = 0.74;  // Ctrl::tail_units = kTailFactor * (total supply)^kTailPower
 constexpr int kDefaultRounds = 14;  // push/relabel rounds per replay, i.e. between two global updates
 constexpr int kDefaultAlphaLog2 = 4;  // epsilon / 16 per phase
+constexpr int kWarmDeclineSteps = 1;  // a warm start whose first epsilon is within this many powers of two of a cold solve's starts cold
 constexpr int kGuIters = 12;     // frontier expansions per replay (multiple of 3)
 constexpr int PSN_EINFEASIBLE_DEV = -4;
 

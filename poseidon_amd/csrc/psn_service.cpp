@@ -949,6 +949,7 @@ int64_t psn_svc_schedule(psn_svc *s) {
         s->st.update_ms = now_ms() - t0;
         warm = true;
     }
+    const bool in_place = warm;  // the network stayed resident: tasks have machines from the round before
     {
         const double t0 = now_ms();
         rc = psn_solve(s->ctx, warm ? PSN_WARM_START : 0u, &res);
@@ -956,7 +957,8 @@ int64_t psn_svc_schedule(psn_svc *s) {
         if (rc != PSN_OK) { s->resident = false; return s->fail(rc, std::string("solve: ") + psn_last_error(s->ctx)); }
     }
     // what the solver did, not what was asked for: a patch that outgrew the cost scale's head-room makes
-    // the solve after it a cold one although the network stayed resident
+    // the solve after it a cold one although the network stayed resident, and so does a kept state that is
+    // no head start (solve_warm_declined)
     warm = res.warm_started != 0;
     s->st.last_round_warm = warm ? 1 : 0;
     if (warm) ++s->st.warm_rounds;
@@ -964,6 +966,7 @@ int64_t psn_svc_schedule(psn_svc *s) {
     s->st.solve_replays = (i64)res.replays; s->st.solve_last_phase_replays = res.last_phase_replays; s->st.solve_refines = res.refines;
     s->st.solve_rounds = (i64)res.rounds; s->st.solve_global_updates = (i64)res.global_updates; s->st.solve_pushes = (i64)res.pushes;
     s->st.solve_first_units = (i64)res.first_units; s->st.solve_first_eps_log2 = res.first_eps_log2; s->st.solve_device_ms = res.solve_ms;
+    s->st.solve_warm_declined = res.warm_declined;
     // ---- placements -> deltas
     const double t0 = now_ms();
     std::vector<int32_t> place((size_t)s->P, -1);
@@ -1020,8 +1023,8 @@ int64_t psn_svc_schedule(psn_svc *s) {
         }
     };
     {
-        // (a cold round has nothing to keep: its matching is too short to be worth the threads' start)
-        const int helpers = warm && s->P >= 20000 && s->E >= 8 ? 3 : 0;
+        // (a first round has nothing to keep: its matching is too short to be worth the threads' start)
+        const int helpers = in_place && s->P >= 20000 && s->E >= 8 ? 3 : 0;
         std::vector<std::thread> pool;
         for (int i = 0; i < helpers; ++i) pool.emplace_back(match_classes);
         match_classes();

@@ -36,7 +36,8 @@ class SvcStats(C.Structure):
                 ("tasks_running", C.c_int64), ("total_ms", C.c_double), ("tasks_deferred", C.c_int64),
                 ("solve_replays", C.c_int64), ("solve_last_phase_replays", C.c_int64), ("solve_refines", C.c_int64),
                 ("solve_rounds", C.c_int64), ("solve_global_updates", C.c_int64), ("solve_pushes", C.c_int64),
-                ("solve_first_units", C.c_int64), ("solve_first_eps_log2", C.c_int64), ("solve_device_ms", C.c_double)]
+                ("solve_first_units", C.c_int64), ("solve_first_eps_log2", C.c_int64), ("solve_device_ms", C.c_double),
+                ("solve_warm_declined", C.c_int64)]
 
 
 class Selector(C.Structure):  # include/psn_service.h psn_selector

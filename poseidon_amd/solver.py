@@ -35,6 +35,7 @@ class SolveResult:
     first_units: int = 0
     first_eps_log2: int = 0
     last_phase_replays: int = 0
+    warm_declined: int = 0
 
     @property
     def algorithmic_bytes(self) -> int:
@@ -166,7 +167,7 @@ class Solver:
         r = _lib.Result()
         rc = self._lib.psn_solve(self._ctx, _lib.PSN_WARM_START if warm_start else 0, C.byref(r))
         self._chk(rc)
-        return SolveResult(*(getattr(r, f[0]) for f in _lib.Result._fields_))
+        return SolveResult(*(getattr(r, f[0]) for f in _lib.Result._fields_ if not f[0].startswith("reserved")))
 
     def flow(self) -> np.ndarray:
         out = np.empty(self.m2, np.int32)

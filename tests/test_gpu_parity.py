@@ -512,6 +512,58 @@ def test_leaf_vertices_that_fetch_their_own_distance(solver):
         assert tc == r.total_cost, (trial, tc, r.total_cost)
 
 
+@pytest.mark.parametrize("decline", [None, "-1", "40"])
+def test_warm_start_that_is_no_head_start_is_declined(solver, monkeypatch, decline):
+    """A kept state that the changes violate by about as much as an empty one (its first epsilon within
+    a power of two of a cold solve's) is declined: the solve starts cold on the resident network and
+    says so.  Slot costs of a solved cluster are changed wholesale (every third class -> machine arc by
+    up to +-2000 of 0..2000) and the network re-solved with PSN_WARM_START: by the default rule, with the
+    rule off (always resumes) and with a rule that always declines - the oracle's optimum of the changed
+    network and a certificate every time; a small change (ten arcs by one unit) is resumed."""
+    if decline is not None:
+        monkeypatch.setenv("PSN_WARM_DECLINE", decline)
+    cl = pa.synth_cluster(0, 2)
+    net = pa.build_network(cl)
+    solver.upload(net)
+    solver.eval_costs(cl, net)
+    r0 = solver.solve()
+    assert r0.warm_declined == 0 and r0.warm_started == 0
+    og = synth.build_graph(synth.make_cluster(0, 2))
+    N, E, K = cl.layout.n_machines, cl.layout.n_classes, cl.layout.k_slots
+    rng = np.random.default_rng(4)
+    P = cl.layout.n_tasks
+    slot = og.fwd_pos[2 * P:2 * P + E * N * K]  # the class -> machine slot arcs (after task -> class and task -> unscheduled)
+    assert ((og.head[slot] >= 1) & (og.head[slot] <= N)).all()
+    slot = slot[og.cap[slot] > 0]
+
+    def change(arcs, delta):
+        newc = np.maximum(0, og.cost[arcs] + delta).astype(np.int32)
+        og.cost[arcs] = newc
+        og.cost[og.rev[arcs]] = -newc
+        solver.update_costs(arcs.astype(np.int64), newc)
+
+    few = rng.choice(slot, 10, replace=False)
+    change(few, np.ones(10, np.int64))
+    r1 = solver.solve(warm_start=True)
+    rc, tc, _, _, _ = capi.cost_scaling(og)
+    assert rc == 0 and r1.total_cost == tc
+    if decline != "40":
+        assert r1.warm_started == 1 and r1.warm_declined == 0
+    many = slot[::3]
+    change(many, rng.integers(-2000, 2001, many.shape[0]))
+    r2 = solver.solve(warm_start=True)
+    rc, tc, _, _, _ = capi.cost_scaling(og)
+    assert rc == 0 and r2.total_cost == tc
+    assert r2.warm_started + r2.warm_declined == 1
+    if decline == "-1":
+        assert r2.warm_started == 1
+    if decline == "40":
+        assert r2.warm_declined == 1 and r1.warm_declined == 1
+    if decline is None:
+        assert r2.warm_declined == 1, (r2.first_eps_log2, r0.first_eps_log2)
+    assert capi.check(og, solver.residual(), solver.prices(), scale=solver.price_scale())[:2] == (0, tc)
+
+
 @pytest.mark.parametrize("shards", ["1", "0"])
 def test_hub_purses_and_sharded_accumulators_on_and_off(monkeypatch, shards):
     """Networks from two million residual arcs keep their hubs' excess in per-hub purses during a push

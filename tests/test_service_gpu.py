@@ -70,7 +70,8 @@ def test_schedule_rounds_cold_then_warm(cfg, seed):
             nxt += ch.pods_replaced.shape[0]
             deltas = s.Schedule()
             st = s.stats()
-            assert st.last_round_warm == 1 and st.rebuilds == 1, "churn inside the head-room must be applied in place"
+            # in place: the solver either resumed from the kept state or declined it as no head start - never a rebuild
+            assert st.last_round_warm + st.solve_warm_declined == 1 and st.rebuilds == 1, "churn inside the head-room must be applied in place"
             assert st.total_cost == oracle_cost(cl)
             live = set(int(u) for u in uids)
             for d in deltas:
@@ -107,7 +108,7 @@ def test_churn_round_at_full_scale():
         uids = apply_churn(s, cl2, ch, uids, int(uids.max()) + 1)
         deltas = s.Schedule()
         st = s.stats()
-        assert st.last_round_warm == 1 and st.rebuilds == 1
+        assert st.last_round_warm + st.solve_warm_declined == 1 and st.rebuilds == 1
         assert st.total_cost == oracle_cost(cl2)
         assert st.patched_arcs > 0 and st.patched_arcs < 40_000  # only what changed crossed PCIe
         new = set(int(u) for u in uids[ch.pods_replaced])
@@ -268,7 +269,7 @@ def test_random_rpc_sequences_scheduled_on_the_gpu(seed):
             random_rpcs(s, rng, st, shapes, int(rng.integers(10, 80)))
             deltas = s.Schedule()
             stt = s.stats()
-            warm += stt.last_round_warm
+            warm += stt.last_round_warm + stt.solve_warm_declined  # rounds applied in place
             assert stt.total_cost == model_cost(st.machines, st.tasks, shapes), (seed, burst)
             for d in deltas:
                 assert d.task_id in st.tasks
