@@ -540,7 +540,7 @@ int ceil_log2(i64 x) {
 
 extern "C" {
 
-int psn_version(void) { return 300; }
+int psn_version(void) { return 310; }
 const char *psn_kernel_list(void) {
     return "k_begin,k_flip,k_saturate,k_gu_init,k_gu_expand,k_gu_apply,k_relabel_compact,k_push";
 }
