@@ -192,7 +192,7 @@ void free_graph_buffers(psn_ctx *c) {
 int enqueue_replay(psn_ctx *c, hipStream_t s) {
     const DevGraph &g = c->g;
     int launches = 0;
-    const int gv = std::max(1, std::min(kGrid, (g.n + kBlock * kVpt - 1) / (kBlock * kVpt)));  // vertex sweeps
+    const int gv = std::max(1, std::min(kGrid, (g.n + kBlock * vpt_of(g.n) - 1) / (kBlock * vpt_of(g.n))));  // vertex sweeps
     const int gv1 = std::max(1, std::min(kGrid, (g.n + kBlock - 1) / kBlock));
     // arc sweeps: enough workgroups for the network, no more (small networks then leave room
     // for the kernels of other contexts running beside them)
@@ -1453,7 +1453,7 @@ int group_enqueue_replay(const std::vector<psn_ctx *> &m, const DevGraph *d_grap
     const unsigned G = (unsigned)m.size();
     int gv = 1, gv1 = 1, gs = 32, launches = 0;
     for (psn_ctx *c : m) {
-        gv = std::max(gv, std::min(kGrid, (c->g.n + kBlock * kVpt - 1) / (kBlock * kVpt)));
+        gv = std::max(gv, std::min(kGrid, (c->g.n + kBlock * 2 - 1) / (kBlock * 2)));
         gv1 = std::max(gv1, std::min(kGrid, (c->g.n + kBlock - 1) / kBlock));
         gs = std::max<int>(gs, (int)std::min<long long>(kGrid, (c->m2 + kBlock * 16 - 1) / (kBlock * 16)));
     }
@@ -2015,7 +2015,7 @@ int psn_debug_gu_bench(psn_ctx *c, int reps, int eps_shift, int sink, int n_expa
     if (!c || !c->uploaded) return PSN_ESTATE;
     HIPCHK(c, hipSetDevice(c->device));
     const DevGraph &g = c->g;
-    const int gv = std::max(1, std::min(kGrid, (g.n + kBlock * kVpt - 1) / (kBlock * kVpt)));
+    const int gv = std::max(1, std::min(kGrid, (g.n + kBlock * vpt_of(g.n) - 1) / (kBlock * vpt_of(g.n))));
     const int gs = (int)std::max<long long>(32, std::min<long long>(kGrid, (c->m2 + kBlock * 16 - 1) / (kBlock * 16)));
     hipStream_t s = c->stream;
     for (int r = 0; r < reps; ++r) {

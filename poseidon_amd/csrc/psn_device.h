@@ -19,7 +19,8 @@ constexpr unsigned kArcPad = 8;   // spare entries after the arc arrays: a lane 
 constexpr unsigned kWSeg = 2 * kStep;  // arcs per wave work item; larger vertices are split into several items
 constexpr unsigned kMedMax = kWSeg;  // degree <= kMedMax: the whole vertex is one wave item
 constexpr unsigned kQCap = 256;  // entries per per-wave LDS frontier staging queue
-constexpr int kVpt = 2;          // vertices per thread in the vertex sweeps
+constexpr int kVptSmallN = 32768; // vertex sweeps: one vertex per thread up to this many vertices, two beyond
+__host__ __device__ constexpr int vpt_of(int n) { return n <= kVptSmallN ? 1 : 2; }
 constexpr int kMaxVertices = 1 << 28;  // lane items pack the degree above bit 28
 constexpr int kClsLow = 0, kClsMed = 1, kClsHigh = 2;  // vertex classes by degree
 constexpr int kClsMask = 3;      // the class in a cls[] byte

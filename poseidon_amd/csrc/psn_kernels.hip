@@ -738,7 +738,8 @@ __device__ __forceinline__ void append_hubs(const HubLds &hl, unsigned count, un
     }
 }
 
-__device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, int do_relabel) {
+template <int kVpt>
+__device__ __forceinline__ void relabel_compact_body_t(const DevGraph &g, int k, int do_relabel) {
     Ctrl *ct = g.ctrl;
     // The first batch of vertex words is asked for before the control words are known: both
     // arrive in one round trip, and a launch that turns out to be switched off just drops them.
@@ -837,6 +838,14 @@ __device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, i
         }
     }
     tally_flush<kTallyRelabels>(g, t);
+}
+
+// A small network solved on its own takes one vertex per thread (twice the workgroups, half the work behind each
+// wait: 1-2 % of a solve); large ones, and the members of a lockstep group (whose launches already hold a hundred
+// networks' workgroups: 5 % the other way), take two.
+__device__ __forceinline__ void relabel_compact_body(const DevGraph &g, int k, int do_relabel) {
+    if (g.n <= kVptSmallN) relabel_compact_body_t<1>(g, k, do_relabel);
+    else relabel_compact_body_t<2>(g, k, do_relabel);
 }
 
 // ------------------------------------------------------------- per-phase saturation
@@ -1343,7 +1352,8 @@ __device__ __forceinline__ void gu_expand_body(const DevGraph &g, int k) {
 }
 
 // dist = 0 at deficits (they seed frontier 0), "infinite" elsewhere.
-__device__ __forceinline__ void gu_init_body(const DevGraph &g) {
+template <int kVpt>
+__device__ __forceinline__ void gu_init_body_t(const DevGraph &g) {
     Ctrl *ct = g.ctrl;
     if (!ct->gu_init_on) return;
     __shared__ AppendLds s_app;
@@ -1366,6 +1376,11 @@ __device__ __forceinline__ void gu_init_body(const DevGraph &g) {
         for (int i = 0; i < kVpt; ++i) { r0[i] = def[i] ? g.row[v[i]] : 0; r1[i] = def[i] ? g.row[v[i] + 1] : 0; }
         block_append<kVpt>(ct->fr_cnt[0], g.fr_low[0], g.fr_seg[0], def, v, cls, r0, r1, rot, s_app);
     }
+}
+
+__device__ __forceinline__ void gu_init_body(const DevGraph &g) {
+    if (g.n <= kVptSmallN) gu_init_body_t<1>(g);
+    else gu_init_body_t<2>(g);
 }
 
 // price[v] -= eps * dist[v]; vertices that reach no deficit move by one more than the
@@ -1860,13 +1875,13 @@ __global__ __launch_bounds__(kBlock) void k_scatter_supply(long long count, cons
 __global__ __launch_bounds__(kBlock) void k_push(DevGraph g, int k) { push_body(g, k); }
 __global__ __launch_bounds__(kBlock) void k_push_group(const DevGraph *__restrict__ gs, int k) { push_body(gs[blockIdx.y], k); }
 __global__ __launch_bounds__(kBlock) void k_relabel_compact(DevGraph g, int k, int do_relabel) { relabel_compact_body(g, k, do_relabel); }
-__global__ __launch_bounds__(kBlock) void k_relabel_compact_group(const DevGraph *__restrict__ gs, int k, int do_relabel) { relabel_compact_body(gs[blockIdx.y], k, do_relabel); }
+__global__ __launch_bounds__(kBlock) void k_relabel_compact_group(const DevGraph *__restrict__ gs, int k, int do_relabel) { relabel_compact_body_t<2>(gs[blockIdx.y], k, do_relabel); }
 __global__ __launch_bounds__(kBlock) void k_saturate(DevGraph g) { saturate_body(g); }
 __global__ __launch_bounds__(kBlock) void k_saturate_group(const DevGraph *__restrict__ gs) { saturate_body(gs[blockIdx.y]); }
 __global__ __launch_bounds__(kBlock, 4) void k_gu_expand(DevGraph g, int k) { gu_expand_body(g, k); }
 __global__ __launch_bounds__(kBlock, 4) void k_gu_expand_group(const DevGraph *__restrict__ gs, int k) { gu_expand_body(gs[blockIdx.y], k); }
 __global__ __launch_bounds__(kBlock) void k_gu_init(DevGraph g) { gu_init_body(g); }
-__global__ __launch_bounds__(kBlock) void k_gu_init_group(const DevGraph *__restrict__ gs) { gu_init_body(gs[blockIdx.y]); }
+__global__ __launch_bounds__(kBlock) void k_gu_init_group(const DevGraph *__restrict__ gs) { gu_init_body_t<2>(gs[blockIdx.y]); }
 __global__ __launch_bounds__(kBlock) void k_gu_apply(DevGraph g, int n_iters) { gu_apply_body(g, n_iters); }
 __global__ __launch_bounds__(kBlock) void k_gu_apply_group(const DevGraph *__restrict__ gs, int n_iters) { gu_apply_body(gs[blockIdx.y], n_iters); }
 __global__ void k_begin(DevGraph g, int n_rounds) { begin_body(g, n_rounds); }
