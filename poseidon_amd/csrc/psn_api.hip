@@ -409,6 +409,41 @@ __global__ void k_cover_count(const unsigned char *in_cover, int n, unsigned *ou
     if ((threadIdx.x & 63) == 0 && c) __hip_atomic_fetch_add(out, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// After a patch: do the tables that follow from the heads (vertex cover, its independent subset, the
+// prefixes of parallel-arc groups, the pull vertices) still stand, so that they need not be made again
+// from all arcs?  Arcs that went away only loosen what the tables claim; an arc (t, h) that is there
+// now must have an endpoint in the cover, must not join two members of the independent subset I nor
+// give a vertex outside the cover a second neighbour in I (h's row is looked through when it is short;
+// a long one counts as broken), must lie behind its row's prefix of parallel groups, and must not
+// give a pull vertex a low-degree neighbour.  broken[0] counts the arcs that fail.
+__device__ __forceinline__ bool independent_subset_stands(const unsigned *row, int n, const int *head, const unsigned char *in_cover,
+                                                          const unsigned char *not_indep, int t, int h) {
+    if (!(in_cover[t] && !not_indep[t])) return true;  // t is not in I: nothing to ask from its side
+    if (in_cover[h]) return not_indep[h] != 0;
+    const unsigned r0 = row[h], r1 = row[h + 1];
+    if (r1 - r0 > 16u) return false;
+    for (unsigned b = r0; b < r1; ++b) {
+        const int x = head[b];
+        if (x != t && x != h && (unsigned)x < (unsigned)n && in_cover[x] && !not_indep[x]) return false;
+    }
+    return true;
+}
+__global__ void k_patch_keeps_tables(const unsigned *row, int n, long long count, const i64 *idx, const int *head, const int *tail,
+                                     const unsigned char *in_cover, const unsigned char *not_indep, const unsigned *lean_stop,
+                                     const int *hub_of, const unsigned char *cls, unsigned *broken) {
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock) {
+        const unsigned a = (unsigned)idx[i];
+        const int t = tail[a], h = head[a];
+        if (h == t || (unsigned)h >= (unsigned)n) continue;  // placeholder self-loop (checked elsewhere)
+        bool ok = in_cover[t] || in_cover[h];
+        ok = ok && independent_subset_stands(row, n, head, in_cover, not_indep, t, h) && independent_subset_stands(row, n, head, in_cover, not_indep, h, t);
+        if (a < lean_stop[t]) ok = false;
+        if (hub_of[t] == kHubPull && (cls[h] & kClsMask) == kClsLow) ok = false;
+        if (hub_of[h] == kHubPull && (cls[t] & kClsMask) == kClsLow) ok = false;
+        if (!ok) atomicAdd(broken, 1u);
+    }
+}
+
 // Cost statistics of the arcs that can carry flow: out[0] = max |cost|, out[1] = number with a
 // negative cost, out[2 + b] = number with 2^(b-1) < cost <= 2^b (b = 0 holds costs 0 and 1).
 __device__ __forceinline__ void cost_stats_body(const DevGraph &g, i64 *out) {
@@ -1040,48 +1075,67 @@ int psn_patch_arcs(psn_ctx *c, int64_t count, const int64_t *arc_index, const in
     if (!c || count < 0 || (count > 0 && (!arc_index || !head || !cap || !cost || !rev))) return fail(c, PSN_EINVAL, "null argument");
     if (!c->uploaded) return fail(c, PSN_ESTATE, "no graph uploaded");
     if (count == 0) return PSN_OK;
+    // 8 n (|cost| + 1) (n + 1) must stay below 4e18: the largest |cost| that does, worked out once
+    const long double cost_room = 4.0e18L / (8.0L * (long double)c->n * (long double)(c->n + 1)) - 1.0L;
+    const int64_t max_abs_cost = cost_room >= 2147483648.0L ? (int64_t)2147483648LL : (cost_room < 0 ? -1 : (int64_t)cost_room);
     for (int64_t i = 0; i < count; ++i) {
         if (arc_index[i] < 0 || arc_index[i] >= c->m2 || rev[i] < 0 || rev[i] >= c->m2 || head[i] < 0 || head[i] >= c->n || cap[i] < 0)
             return fail(c, PSN_EINVAL, "patched arc out of range");
         const int64_t ac = cost[i] < 0 ? -(int64_t)cost[i] : cost[i];
-        const long double bound = 8.0L * (long double)c->n * (long double)(ac + 1) * (long double)(c->n + 1);
-        if (bound > 4.0e18L) return fail(c, PSN_EOVERFLOW, "n^2 * |cost| too large for int64 prices");
+        if (ac > max_abs_cost) return fail(c, PSN_EOVERFLOW, "n^2 * |cost| too large for int64 prices");
     }
+    const bool dbg_t = std::getenv("PSN_DEBUG_SVC") != nullptr;
+    auto now_p = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tp0 = now_p();
     HIPCHK(c, hipSetDevice(c->device));
     // one staging block: indices (8 B) then four int arrays
-    const size_t bytes = (size_t)count * (sizeof(i64) + 4 * sizeof(int)) + sizeof(unsigned);
+    const size_t bytes = (size_t)count * (sizeof(i64) + 4 * sizeof(int)) + 2 * sizeof(unsigned);
     char *d;
     { const int rcs = stage(c, bytes, &d); if (rcs != PSN_OK) return rcs; }
     i64 *d_idx = (i64 *)d;
     int *d_h = (int *)(d + (size_t)count * sizeof(i64)), *d_c = d_h + count, *d_k = d_c + count, *d_r = d_k + count;
-    unsigned *d_bad = (unsigned *)(d_r + count);
+    unsigned *d_bad = (unsigned *)(d_r + count);  // [0] arcs that do not pair up, [1] arcs that break the tables made from the heads
     hipStream_t s = c->stream;
     hipError_t e = hipMemcpyAsync(d_idx, arc_index, (size_t)count * sizeof(i64), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_h, head, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_c, cap, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_k, cost, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_r, rev, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(unsigned), s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 2 * sizeof(unsigned), s);
     unsigned bad = 0;
     if (e == hipSuccess) {
         const int grid = (int)std::min<long long>((count + kBlock - 1) / kBlock, 1024);
         hipLaunchKernelGGL(k_patch_arcs, dim3(grid), dim3(kBlock), 0, s, c->g, (long long)count, d_idx, d_h, d_c, d_k, d_r, c->d_head,
                            c->d_cost, c->d_rev, c->d_ocap);
         hipLaunchKernelGGL(k_check_patched, dim3(grid), dim3(kBlock), 0, s, c->g, (long long)count, d_idx, d_bad);
+        hipLaunchKernelGGL(k_patch_keeps_tables, dim3(grid), dim3(kBlock), 0, s, c->g.row, c->g.n, (long long)count, d_idx, c->g.head, c->g.tail,
+                           c->d_in_cover, c->d_not_indep, c->d_lean_stop, c->d_hub_of, c->d_cls, d_bad + 1);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(c->h_flag, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_flag + 4, d_bad + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s);
     c->layout_ok_gen = ~0ull;  // pairings change: the slot-block layout is verified again by the next pricing
-    if (e == hipSuccess) { const int rcl = launch_cover(c); if (rcl != PSN_OK) return rcl; }  // rewired arcs may have grown the vertex cover (the error text is launch_cover's)
+    // The tables made from the heads (vertex cover and what goes with it: four sweeps over all arcs, 0.7 ms
+    // at 13 M) are made again only if a patched arc breaks one of them (PSN_PATCH_TABLES=1: always).
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    bool tables_again = false;
+    if (e == hipSuccess && c->h_flag[0] == 0 && (c->h_flag[4] != 0 || std::getenv("PSN_PATCH_TABLES"))) {
+        tables_again = true;
+        const int rcl = launch_cover(c);  // (the error text is launch_cover's)
+        if (rcl != PSN_OK) return rcl;
+        e = hipStreamSynchronize(s);
+    }
+    if (dbg_t) fprintf(stderr, "    patch_arcs: %.3f ms, tables made again: %d\n", now_p() - tp0, (int)tables_again);
     if (e != hipSuccess) return fail(c, PSN_EDEVICE, "psn_patch_arcs", e);
     bad = c->h_flag[0];
     if (bad) {
         c->uploaded = c->solved = false;  // the device network is inconsistent: upload again
         return fail(c, PSN_EINVAL, "patched arcs do not pair up; the network must be uploaded again");
     }
-    c->cover_size = (long long)c->h_flag[2];
-    c->noni_size = (long long)c->h_flag[3];
+    if (tables_again) {
+        c->cover_size = (long long)c->h_flag[2];
+        c->noni_size = (long long)c->h_flag[3];
+    }
     if (c->cover_size > c->cover_cap || c->noni_size > c->noni_cap) {
         // longer residual cycles are possible now: a larger cost scale, under which the kept prices mean
         // nothing, so the next solve starts cold; the replay graph carries the scale and is captured anew

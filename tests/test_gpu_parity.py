@@ -512,6 +512,60 @@ def test_leaf_vertices_that_fetch_their_own_distance(solver):
         assert tc == r.total_cost, (trial, tc, r.total_cost)
 
 
+@pytest.mark.parametrize("always", [False, True])
+def test_rewired_arcs_keep_or_remake_the_tables_made_from_the_heads(monkeypatch, always):
+    """psn_patch_arcs makes the vertex cover, its independent subset and the other tables that follow
+    from the heads again only when a patched arc breaks one of them.  Random graphs (a ring of wide,
+    dear arcs keeps every supply routable) have the heads of two arcs exchanged - u -> v, x -> y become
+    u -> y, x -> v, with their reverse arcs re-paired - several times in a row; after every exchange the
+    solve (cold, and the kept state offered) ends at the oracle's optimum of the rewired graph with a
+    certificate: by the rule, and with the tables made again after every patch."""
+    if always:
+        monkeypatch.setenv("PSN_PATCH_TABLES", "1")
+    rng = np.random.default_rng(99)
+    with pa.Solver(device=0) as s:
+        for trial in range(6):
+            n = int(rng.integers(12, 120))
+            m = int(rng.integers(2 * n, 6 * n))
+            tail = rng.integers(0, n, m)
+            head = (tail + rng.integers(1, n, m)) % n
+            cap = rng.integers(1, 6, m)
+            cost = rng.integers(0, 40, m)
+            f = rng.integers(0, cap + 1)
+            supply = np.zeros(n, np.int64)
+            np.add.at(supply, tail, f)
+            np.add.at(supply, head, -f)
+            ring = np.arange(n)
+            tail = np.concatenate([tail, ring, (ring + 1) % n])
+            head = np.concatenate([head, (ring + 1) % n, ring])
+            cap = np.concatenate([cap, np.full(2 * n, 10_000)])
+            cost = np.concatenate([cost, np.full(2 * n, 500)])
+            g = synth.graph_from_arcs(n, tail, head, cap, cost, supply)
+            s.upload_csr(g.n, g.row_off, g.head, g.cap, g.cost, g.rev, g.supply)
+            for step in range(4):
+                r = s.solve(warm_start=step > 0)
+                rc, tc, _, _ = capi.ssp(g)
+                assert rc == 0 and r.total_cost == tc, (trial, step, always)
+                assert capi.check(g, s.residual(), s.prices(), scale=s.price_scale())[:2] == (0, tc)
+                # exchange the heads of two of the random arcs (forward arcs i and j of the list)
+                i, j = (int(x) for x in rng.choice(m, 2, replace=False))
+                a, b = int(g.fwd_pos[i]), int(g.fwd_pos[j])
+                ra, rb = int(g.rev[a]), int(g.rev[b])
+                u, v, x, y = int(tail[i]), int(g.head[a]), int(tail[j]), int(g.head[b])
+                if u == y or x == v:
+                    continue  # would make a self-loop
+                ca, cb = int(g.cost[a]), int(g.cost[b])
+                # a: u -> y paired with rb (in y's row, now y -> u); b: x -> v paired with ra (in v's row, now v -> x)
+                idx = np.array([a, rb, b, ra], np.int64)
+                nh = np.array([y, u, v, x], np.int32)
+                nc = np.array([g.cap[a] + g.cap[ra], 0, g.cap[b] + g.cap[rb], 0], np.int32)  # original capacities, no flow
+                nk = np.array([ca, -ca, cb, -cb], np.int32)
+                nr = np.array([rb, a, ra, b], np.int32)
+                assert s._lib.psn_patch_arcs(s._ctx, 4, idx.ctypes.data, nh.ctypes.data, nc.ctypes.data, nk.ctypes.data, nr.ctypes.data) == 0
+                g.head[idx] = nh; g.cap[idx] = nc; g.cost[idx] = nk; g.rev[idx] = nr
+                head[i], head[j] = y, v
+
+
 @pytest.mark.parametrize("decline", [None, "-1", "40"])
 def test_warm_start_that_is_no_head_start_is_declined(solver, monkeypatch, decline):
     """A kept state that the changes violate by about as much as an empty one (its first epsilon within
