@@ -980,14 +980,19 @@ int64_t psn_svc_schedule(psn_svc *s) {
     s->st.solve_warm_declined = res.warm_declined;
     // ---- placements -> deltas
     const double t0 = now_ms();
+    const bool dbg_x = std::getenv("PSN_DEBUG_SVC") != nullptr;
+    double tx = t0;
+    auto lapx = [&](const char *what) { if (dbg_x) { const double t = now_ms(); fprintf(stderr, "  extract: %-10s %.3f ms\n", what, t - tx); tx = t; } };
     std::vector<int32_t> place((size_t)s->P, -1);
     rc = psn_get_placements(s->ctx, &s->lay, place.data());
     if (rc != PSN_OK) return s->fail(rc, std::string("placements: ") + psn_last_error(s->ctx));
+    lapx("placements");
     // Tasks of a class are interchangeable: hand each class's routed units first to the tasks
     // that already sit on the unit's machine, so that an unchanged optimum yields no deltas.
     std::vector<std::vector<int>> members((size_t)s->E);
     for (int t = 0; t < s->P; ++t)
         if (s->slot_used[(size_t)t]) members[(size_t)s->slot_task[(size_t)t]->cls].push_back(t);
+    lapx("members");
     i64 placed = 0;
     std::vector<int32_t> final_place((size_t)s->P, -1);
     // Classes are independent of each other here (a task belongs to one class and final_place is
@@ -1047,6 +1052,7 @@ int64_t psn_svc_schedule(psn_svc *s) {
     // over-commits a machine (the slot arcs that do not fit have no capacity), two classes placed on
     // one machine in the same round can; the task that does not fit stays pending and is priced
     // against the new usage next round.
+    lapx("matching");
     const bool keep = s->keep_running();
     std::vector<std::pair<Task *, int>> to_pin;
     std::vector<i64> free_cpu, free_mem;
@@ -1085,6 +1091,7 @@ int64_t psn_svc_schedule(psn_svc *s) {
         if ((i64)to_pin.size() * 4 > s->attached) s->need_layout = true;
         for (auto &pr : to_pin) s->pin(*pr.first, pr.second);
     }
+    lapx("deltas");
     s->st.extract_ms = now_ms() - t0;
     s->st.tasks_placed = placed;
     s->st.tasks_running = s->pinned_total;
